@@ -1,0 +1,197 @@
+"""
+Headline benchmark: patches/sec through one training step = 200-iteration
+FISTA inference + one dictionary update, 16x16 patches (n=256), 1024-atom
+dictionary (BASELINE.json configs[1]; configs[2] when launched on N GPUs).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+      --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU.  The patch batch shards by rows over the ranks (weak
+scaling: --batch patches per GPU); inference is rank-local; the un-normalised
+dictionary gradient is summed with one RCCL all-reduce per step.  Rank 0 prints
+ONE JSON line.  Inputs are synthetic (numpy RandomState) and resident in HBM
+before the timed region starts.
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / 'vision-transform-codes_amd'))
+
+N_PIX = 256          # 16 x 16 patches
+N_ATOMS = 1024       # 4x overcomplete
+FISTA_ITERS = 200
+LAMBDA = 0.008       # examples/train_sparse_coding.py:59 of the reference
+DICT_STEP = 0.1
+FLOP_PER_PATCH_ITER = 4 * N_ATOMS * N_PIX     # two contractions of 2*s*n
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
+PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3}
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--batch', type=int, default=0,
+                  help='patches per GPU (0 = default for the precision)')
+  ap.add_argument('--precision', default='auto',
+                  choices=['auto', 'f32', 'bf16x3', 'bf16'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-sample', type=int, default=2048,
+                  help='patches in the CPU-baseline sample')
+  return ap.parse_args()
+
+
+def synthetic_inputs(rank, batch, device):
+  """X = 0.1 N(0,1) (seed = rank, so shards differ), D = N(0,1) rows
+  normalised (seed 1, identical on every rank)."""
+  X = (0.1 * np.random.RandomState(1000 + rank).randn(batch, N_PIX)).astype(
+      np.float32)
+  D = np.random.RandomState(1).randn(N_ATOMS, N_PIX).astype(np.float32)
+  D /= np.linalg.norm(D, axis=1, keepdims=True)
+  return torch.from_numpy(X).to(device), torch.from_numpy(D).to(device)
+
+
+def cpu_baseline(sample):
+  """The CPU oracle (torch CPU float32 ops in the reference's op order) timed
+  on this box's host cores on a bounded sample of the same workload."""
+  sys.path.insert(0, str(REPO / 'oracle'))
+  import sc_oracle
+  cores = os.cpu_count() or 1
+  try:
+    cores = len(os.sched_getaffinity(0))
+  except AttributeError:
+    pass
+  torch.set_num_threads(cores)
+  X = torch.from_numpy((0.1 * np.random.RandomState(0).randn(
+      sample, N_PIX)).astype(np.float32))
+  D = np.random.RandomState(1).randn(N_ATOMS, N_PIX).astype(np.float32)
+  D = torch.from_numpy(D / np.linalg.norm(D, axis=1, keepdims=True))
+  best = float('inf')
+  deadline = time.time() + 25.0
+  runs = 0
+  while runs < 3 and time.time() < deadline:
+    t0 = time.time()
+    codes = sc_oracle.fc_ista_fista(X, D, LAMBDA, FISTA_ITERS, variant='fista')
+    sc_oracle.fc_steepest_descent(X, D.clone(), codes, stepsize=DICT_STEP)
+    best = min(best, time.time() - t0)
+    runs += 1
+  return {'value': sample / best, 'unit': 'patches/s', 'cores': cores,
+          'kind': 'port',
+          'sample': '%d patches x %d-iter FISTA + 1 update, best of %d, '
+                    'torch %d threads' % (sample, FISTA_ITERS, runs, cores)}
+
+
+def main():
+  args = parse_args()
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  assert world == args.gpus, 'launch one process per GPU (--gpus == WORLD_SIZE)'
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+
+  import vtc_hip
+  from vtc_hip import parallel
+  from analysis_transforms.fully_connected import ista_fista
+  from dict_update_rules.fully_connected import sc_steepest_descent
+
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=device)
+    parallel.enable()
+
+  precision = args.precision
+  if precision == 'auto':
+    precision = 'bf16x3' if ista_fista.fused_available() else 'f32'
+  batch = args.batch or (131072 if precision != 'f32' else 32768)
+  X, D = synthetic_inputs(rank, batch, device)
+
+  inf_start = torch.cuda.Event(enable_timing=True)
+  inf_stop = torch.cuda.Event(enable_timing=True)
+  inference_ms = []
+
+  def step(timed):
+    if timed:
+      inf_start.record()
+    codes = ista_fista.run(X, D, LAMBDA, FISTA_ITERS, variant='fista',
+                           precision=precision)
+    if timed:
+      inf_stop.record()
+    sc_steepest_descent.run(X, D, codes, stepsize=DICT_STEP, num_iters=1)
+    return codes
+
+  def fence():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step(False)
+  fence()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step(True)
+    # events are read after the loop; recording them does not sync
+    inference_ms.append((inf_start, inf_stop))
+    inf_start = torch.cuda.Event(enable_timing=True)
+    inf_stop = torch.cuda.Event(enable_timing=True)
+  fence()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    worst = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    elapsed = float(worst.item())
+
+  kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in inference_ms]))
+  total_patches = batch * world * args.steps
+  value = total_patches / elapsed
+  achieved = batch * FISTA_ITERS * FLOP_PER_PATCH_ITER / (kernel_ms * 1e-3) / 1e12
+  peak = PEAK_TFLOPS[precision]
+  result = {
+      'metric': 'patches/sec through 200-iter FISTA + dict update, '
+                '1024-atom dict',
+      'value': value, 'unit': 'patches/s', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': 1e3 * elapsed / args.steps,
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': precision, 'data': 'synthetic',
+      'config': {'workload': '16x16 patches (n=256), 1024-atom dictionary, '
+                             '200-iter FISTA + 1 steepest-descent update',
+                 'patches_per_gpu': batch, 'global_batch': batch * world,
+                 'parallelism': 'dp%d' % world,
+                 'collective': 'all-reduce of the 1 MiB dictionary gradient '
+                               'per step' if world > 1 else 'none'},
+      'roofline': {
+          'bound': 'mfma',
+          'kernel': 'FISTA inference launch(es): %d iterations of the two '
+                    'contractions with fused shrink/momentum' % FISTA_ITERS,
+          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+          'frac': achieved / peak, 'traffic': None,
+          'ms_per_launch': kernel_ms,
+          'flops_per_launch': batch * FISTA_ITERS * FLOP_PER_PATCH_ITER},
+  }
+  if rank == 0:
+    if world == 1 and not args.no_cpu_baseline:
+      result['cpu_baseline'] = cpu_baseline(args.cpu_sample)
+    else:
+      result['cpu_baseline'] = None
+    print(json.dumps(result))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,212 @@
+/*
+ * vtc_hip.h -- C ABI of the MI355X (gfx950) sparse-coding engine.
+ *
+ * One shared library, libvtc_hip.so, replaces the arithmetic behind the
+ * plugin layer of spencerkent/vision-transform-codes:
+ *
+ *   analysis_transforms/fully_connected/ista_fista.py:14-148          -> vtc_fc_ista_fista
+ *   analysis_transforms/fully_connected/subspace_ista_fista.py:23-192 -> vtc_subspace_ista_fista
+ *                                                                        (+ vtc_group_gather_rows / vtc_group_gather_cols /
+ *                                                                           vtc_group_scatter_add)
+ *   analysis_transforms/convolutional/ista_fista.py:18-197            -> vtc_conv_ista_fista
+ *   dict_update_rules/fully_connected/sc_steepest_descent.py:9-41,
+ *     sc_cheap_quadratic_descent.py:11-48,
+ *     subspace_sc_cheap_quadratic_descent.py:13-127                   -> vtc_fc_dict_gradient, vtc_subspace_alignment_gradient,
+ *                                                                        vtc_fc_dict_apply
+ *   dict_update_rules/convolutional/sc_steepest_descent.py:12-72,
+ *     sc_cheap_quadratic_descent.py:14-79                             -> vtc_conv_dict_gradient, vtc_conv_dict_apply
+ *   training/sparse_coding.py:154,160-161 (Hessian-diagonal EMA)      -> vtc_code_energy, vtc_hessian_ema
+ *   the `torch.mm(dictionary.t(), dictionary)` of the Lipschitz step
+ *     (ista_fista.py:73-74)                                           -> vtc_gram
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless
+ *     said otherwise; sizes are element counts; `stream` is a hipStream_t
+ *     passed as void* (NULL = the null stream).
+ *   - functions only enqueue work on `stream` and return; the single exception
+ *     is an inference call with early_stopping_epsilon >= 0, which has to read
+ *     one flag back per iteration exactly like the reference's
+ *     `stop_early = (avg < eps)` does (ista_fista.py:143-144).
+ *   - no allocation inside: scratch comes from the caller as `workspace`, sized
+ *     by the matching *_workspace_bytes() query.
+ *   - return value: VTC_OK or a VTC_ERR_* code; vtc_last_error() gives text.
+ *   - the gradient/apply split of the dictionary update is where a data-parallel
+ *     caller places its all-reduce: gradient sums are un-normalised sums over
+ *     the local batch, `global_batch` in the apply call is the divisor.
+ */
+#ifndef VTC_HIP_H_
+#define VTC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTC_ABI_VERSION 1
+
+enum vtc_status {
+  VTC_OK = 0,
+  VTC_ERR_INVALID_ARGUMENT = 1, /* bad size / enum / null pointer           */
+  VTC_ERR_UNSUPPORTED = 2,      /* valid in the reference, not built here    */
+  VTC_ERR_WORKSPACE = 3,        /* workspace too small                       */
+  VTC_ERR_HIP = 4               /* a HIP runtime call failed                 */
+};
+
+enum vtc_variant { VTC_ISTA = 0, VTC_FISTA = 1 };
+
+/* ista_fista.py:107-120 */
+enum vtc_threshold {
+  VTC_SOFT = 0,        /* sign(c) * max(|c| - lambda*eta, 0)                 */
+  VTC_SOFT_NONNEG = 1, /* max(c - lambda*eta, 0)                             */
+  VTC_HARD = 2,        /* c if |c| >= lambda*eta else 0                      */
+  VTC_HARD_NONNEG = 3  /* c if c >= lambda*eta else 0                        */
+};
+
+/* arithmetic used by the two contractions of an inference iteration */
+enum vtc_precision {
+  VTC_F32 = 0,    /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode    */
+  VTC_BF16X3 = 1, /* bf16 hi/lo split, 3 MFMA products: ~f32 accuracy        */
+  VTC_BF16 = 2    /* single bf16 MFMA product, f32 accumulate: fast mode     */
+};
+
+const char* vtc_version(void);
+const char* vtc_last_error(void);
+int vtc_abi_version(void);
+
+/* ---- Lipschitz step ---------------------------------------------------- */
+/* gram = A^T A (transpose_a = 1, A is (rows, cols), gram is (cols, cols)) or
+ * A A^T (transpose_a = 0, gram is (rows, rows)).  ista_fista.py:73-74 uses the
+ * first form on the (s, n) dictionary, convolutional/ista_fista.py:104-105 the
+ * second on the (s, c*kh*kw) flattened kernels. */
+int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
+             float* gram, void* stream);
+
+/* ---- fully-connected inference (row a1) ------------------------------- */
+size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n, int64_t s,
+                                         int precision);
+/* images (b,n), dictionary (s,n), initial_codes (b,s) or NULL, codes (b,s) out.
+ * stepsize = eta = 1/L.  The threshold is float(sparsity_weight)*eta in f32.
+ * early_stopping_epsilon < 0 disables the stopping test (sync-free).
+ * iters_run (host int*, may be NULL) receives the iterations executed. */
+int vtc_fc_ista_fista(const float* images, const float* dictionary,
+                      const float* initial_codes, float* codes, int64_t b,
+                      int64_t n, int64_t s, float stepsize,
+                      float sparsity_weight, int num_iters, int variant,
+                      int threshold, float early_stopping_epsilon,
+                      int precision, void* workspace, size_t workspace_bytes,
+                      int* iters_run, void* stream);
+
+/* ---- subspace inference (row a3) --------------------------------------- */
+/* index/valid describe the padded (G, m) layout: slot g*m+j holds dictionary
+ * row index[g*m+j] when valid[g*m+j] != 0 and is padding otherwise. */
+int vtc_group_gather_rows(const float* dictionary, const int32_t* index,
+                          const uint8_t* valid, float* grouped_dictionary,
+                          int64_t slots, int64_t n, void* stream);
+int vtc_group_gather_cols(const float* codes, const int32_t* index,
+                          const uint8_t* valid, float* grouped_codes,
+                          int64_t b, int64_t s, int64_t slots, void* stream);
+/* codes (b,s): codes[:, a] = sum of grouped_codes[:, t] over the slots t of
+ * atom a, listed in increasing order in CSR form: atom_slots[atom_ptr[a] ..
+ * atom_ptr[a+1]) (subspace_ista_fista.py:184-190 adds them in that order). */
+int vtc_group_scatter_add(const float* grouped_codes, const int32_t* atom_ptr,
+                          const int32_t* atom_slots, float* codes, int64_t b,
+                          int64_t s, int64_t slots, void* stream);
+size_t vtc_subspace_ista_fista_workspace_bytes(int64_t b, int64_t n,
+                                               int64_t groups, int64_t m);
+/* grouped_dictionary (G*m, n); initial_grouped (b, G*m) or NULL;
+ * grouped_codes (b, G*m) out.  Proximal step scales each group of m slots by
+ * max(1 - lambda*eta/||group||_2, 0) (subspace_ista_fista.py:149-156). */
+int vtc_subspace_ista_fista(const float* images,
+                            const float* grouped_dictionary,
+                            const float* initial_grouped, float* grouped_codes,
+                            int64_t b, int64_t n, int64_t groups, int64_t m,
+                            float stepsize, float sparsity_weight,
+                            int num_iters, int variant,
+                            float early_stopping_epsilon, void* workspace,
+                            size_t workspace_bytes, int* iters_run,
+                            void* stream);
+
+/* ---- convolutional inference (row a4) ---------------------------------- */
+typedef struct vtc_conv_geometry {
+  int64_t b;            /* images in the batch                               */
+  int32_t c, h, w;      /* channels, padded height, padded width             */
+  int32_t s, kh, kw;    /* kernels, kernel height, kernel width              */
+  int32_t stride_v, stride_h;
+  int32_t has_padding;  /* 0: padding_dims was None (mask of ones)           */
+  int32_t pad_lead_v, pad_trail_v, pad_lead_h, pad_trail_h;
+} vtc_conv_geometry;
+
+int vtc_conv_code_dims(const vtc_conv_geometry* g, int32_t* code_h,
+                       int32_t* code_w);
+size_t vtc_conv_ista_fista_workspace_bytes(const vtc_conv_geometry* g);
+/* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w) */
+int vtc_conv_ista_fista(const float* images_padded, const float* dictionary,
+                        const float* initial_codes, float* codes,
+                        const vtc_conv_geometry* g, float stepsize,
+                        float sparsity_weight, int num_iters, int variant,
+                        int threshold, float early_stopping_epsilon,
+                        void* workspace, size_t workspace_bytes,
+                        int* iters_run, void* stream);
+
+/* ---- dictionary update, fully-connected (rows a5, a6, a7) --------------- */
+size_t vtc_fc_dict_gradient_workspace_bytes(int64_t b, int64_t n, int64_t s);
+/* grad_sum (s,n) = codes^T (codes dictionary - images): NOT divided by b. */
+int vtc_fc_dict_gradient(const float* images, const float* dictionary,
+                         const float* codes, float* grad_sum, int64_t b,
+                         int64_t n, int64_t s, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* penalty_grad (s,n) = sum over groups of the |cos| alignment gradients
+ * (subspace_sc_cheap_quadratic_descent.py:91-127); index/valid and the CSR
+ * inverse map atom_ptr/atom_slots as above.  Groups of up to 32 atoms. */
+size_t vtc_subspace_alignment_gradient_workspace_bytes(int64_t slots,
+                                                       int64_t n);
+int vtc_subspace_alignment_gradient(
+    const float* dictionary, const int32_t* index, const uint8_t* valid,
+    const int32_t* atom_ptr, const int32_t* atom_slots, float* penalty_grad,
+    int64_t s, int64_t n, int64_t groups, int64_t m, int dict_is_normalized,
+    void* workspace, size_t workspace_bytes, void* stream);
+/* D -= (stepsize * (grad_sum/global_batch + alignment_penalty*penalty_grad))
+ *      / (hessian_diagonal + lowest_code_val)         [divide iff hessian given]
+ * then D /= ||row||_2 iff normalize.  hessian_diagonal, penalty_grad may be
+ * NULL.  In place on `dictionary` (s,n). */
+int vtc_fc_dict_apply(float* dictionary, const float* grad_sum,
+                      const float* hessian_diagonal, const float* penalty_grad,
+                      float alignment_penalty, int64_t global_batch,
+                      float stepsize, float lowest_code_val, int normalize,
+                      int64_t s, int64_t n, void* stream);
+
+/* ---- dictionary update, convolutional (rows a8, a9) --------------------- */
+size_t vtc_conv_dict_gradient_workspace_bytes(const vtc_conv_geometry* g);
+/* grad_sum (s,c,kh,kw) = sum_{b,p,q} codes[b,s,p,q] * r[b,c,p*sv+dy,q*sh+dx],
+ * r = mask * (synthesis(codes) - images_padded): NOT divided by b. */
+int vtc_conv_dict_gradient(const float* images_padded, const float* dictionary,
+                           const float* codes, float* grad_sum,
+                           const vtc_conv_geometry* g, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* g = grad_sum/global_batch; g /= (h + lowest_code_val) iff hessian given;
+ * g *= ||D||_F/||g||_F; D -= stepsize*g; per-kernel l2 normalise iff normalize.
+ * scratch: s*kernel_elems floats of device memory. */
+int vtc_conv_dict_apply(float* dictionary, const float* grad_sum,
+                        const float* hessian_diagonal, int64_t global_batch,
+                        float stepsize, float lowest_code_val, int normalize,
+                        int64_t s, int64_t kernel_elems, float* scratch,
+                        void* stream);
+
+/* ---- Hessian-diagonal EMA (training/sparse_coding.py:154,160-161) ------- */
+size_t vtc_code_energy_workspace_bytes(int64_t b, int64_t s,
+                                       int64_t positions);
+/* energy[j] = sum_b sum_positions codes[b, j, :]^2  (positions = 1 for the
+ * fully-connected (b,s) layout, code_h*code_w for (b,s,h,w)). */
+int vtc_code_energy(const float* codes, int64_t b, int64_t s,
+                    int64_t positions, float* energy, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* h = 0.99*h + (energy/global_batch)/100 */
+int vtc_hessian_ema(float* hessian_diagonal, const float* energy,
+                    int64_t global_batch, int64_t s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTC_HIP_H_ */

@@ -1,0 +1,105 @@
+"""Convolutional inference and dictionary updates on the GPU vs golden."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import sc_oracle
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = ('k16s8', 'k11s1', 'k8s4_ragged')
+
+
+@pytest.fixture(scope='module')
+def plugins():
+  from analysis_transforms.convolutional import ista_fista
+  from dict_update_rules.convolutional import sc_steepest_descent
+  from dict_update_rules.convolutional import sc_cheap_quadratic_descent
+  return ista_fista, sc_steepest_descent, sc_cheap_quadratic_descent
+
+
+def _case(g, name, device):
+  imgs = helpers.to_dev(g[name + '_images_padded'], device)
+  D = helpers.to_dev(g[name + '_dictionary'].copy(), device)
+  stride = tuple(int(v) for v in g[name + '_stride'])
+  pad = tuple(tuple(int(v) for v in row) for row in g[name + '_padding'])
+  return imgs, D, stride, pad
+
+
+@pytest.mark.parametrize('name', GEOMS)
+def test_inference_matches_reference(device, plugins, name):
+  conv = plugins[0]
+  g = helpers.load('conv')
+  imgs, D, stride, pad = _case(g, name, device)
+  imgs0, D0 = imgs.clone(), D.clone()
+  for variant in ('ista', 'fista'):
+    codes = conv.run(imgs, D, stride, pad, 0.05, 10, variant=variant)
+    helpers.assert_codes_match(codes.cpu().numpy(),
+                               g['%s_codes_%s' % (name, variant)], 2e-5,
+                               name + ' ' + variant, max_flip_mag=1e-5)
+  codes = conv.run(imgs, D, stride, pad, 0.05, 10, variant='ista',
+                   nonnegative_only=True, hard_threshold=True)
+  helpers.assert_codes_match(codes.cpu().numpy(),
+                             g[name + '_codes_ista_hard_nonneg'], 2e-5,
+                             name + ' hard nonneg', max_flip_mag=1e-5)
+  assert torch.equal(imgs, imgs0) and torch.equal(D, D0)
+  init = codes.clone()
+  warm = conv.run(imgs, D, stride, pad, 0.05, 10, variant='ista',
+                  initial_codes=codes, nonnegative_only=True,
+                  hard_threshold=True)
+  assert torch.equal(codes, init)
+  assert not torch.allclose(warm, init)
+
+
+@pytest.mark.parametrize('name', GEOMS)
+def test_dictionary_updates_match_reference(device, plugins, name):
+  _, steepest, cheapquad = plugins
+  g = helpers.load('conv')
+  imgs, D, stride, pad = _case(g, name, device)
+  C = helpers.to_dev(g[name + '_codes_fista'], device)
+  assert steepest.run(imgs, D, C, stride, pad, stepsize=0.005) is None
+  assert helpers.rel_err(D.cpu().numpy(),
+                         g[name + '_dict_after_steepest']) < 5e-6
+  _, D, _, _ = _case(g, name, device)
+  cheapquad.run(imgs, D, C, helpers.to_dev(g[name + '_hessian'], device),
+                stride, pad, stepsize=0.005)
+  assert helpers.rel_err(D.cpu().numpy(),
+                         g[name + '_dict_after_cheapquad']) < 5e-6
+  norms = D.reshape(D.shape[0], -1).norm(dim=1).cpu().numpy()
+  assert np.allclose(norms, 1.0, atol=1e-6)
+
+
+def test_multichannel_no_padding_and_early_stop(device, plugins):
+  """c = 3, padding_dims None, early stopping -- against the oracle."""
+  conv = plugins[0]
+  rs = np.random.RandomState(70)
+  imgs = (0.5 * rs.randn(2, 3, 28, 36)).astype(np.float32)
+  D = rs.randn(7, 3, 4, 6).astype(np.float32)
+  D /= np.sqrt((D.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[
+      :, None, None, None].astype(np.float32)
+  stride = (2, 3)
+  eta = sc_oracle.conv_stepsize(torch.from_numpy(D))
+  ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D),
+                                  stride, None, 0.05, 15, stepsize=eta)
+  codes = conv.run(helpers.to_dev(imgs, device), helpers.to_dev(D, device),
+                   stride, None, 0.05, 15, stepsize=float(eta))
+  helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), 2e-5,
+                             'c=3 no padding', max_flip_mag=1e-5)
+  ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D),
+                                  stride, None, 0.05, 300, variant='ista',
+                                  early_stopping_epsilon=2e-2, stepsize=eta)
+  codes = conv.run(helpers.to_dev(imgs, device), helpers.to_dev(D, device),
+                   stride, None, 0.05, 300, variant='ista',
+                   early_stopping_epsilon=2e-2, stepsize=float(eta))
+  assert 1 < conv.run.last_iters < 300
+  helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), 1e-4,
+                             'early stop', max_flip_mag=1e-4)
+
+
+def test_geometry_mismatch_is_an_error(device, plugins):
+  conv = plugins[0]
+  imgs = torch.zeros(1, 1, 36, 36, device=device)   # (36-6) % 4 != 0
+  D = torch.ones(2, 1, 6, 6, device=device)
+  with pytest.raises(ValueError):
+    conv.run(imgs, D, (4, 4), ((2, 4), (2, 4)), 0.1, 2, stepsize=0.1)

@@ -1,0 +1,158 @@
+"""Host-side logic that needs no GPU: option mapping, group index tables,
+convolution geometry, the data-parallel helpers (gloo, world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+import sc_oracle
+
+
+def test_threshold_and_variant_codes():
+  import vtc_hip
+  assert vtc_hip.threshold_mode(False, False) == vtc_hip.SOFT
+  assert vtc_hip.threshold_mode(True, False) == vtc_hip.SOFT_NONNEG
+  assert vtc_hip.threshold_mode(False, True) == vtc_hip.HARD
+  assert vtc_hip.threshold_mode(True, True) == vtc_hip.HARD_NONNEG
+  assert vtc_hip.variant_code('ista') == vtc_hip.ISTA
+  assert vtc_hip.variant_code('fista') == vtc_hip.FISTA
+  with pytest.raises(AssertionError):
+    vtc_hip.variant_code('lista')
+
+
+def test_group_tables_match_oracle_layout():
+  from vtc_hip import groups as group_tables
+  groups = [[0, 2, 5], [1], [2, 3, 4, 5]]
+  t = group_tables.GroupTables(groups, 6, torch.device('cpu'))
+  gather_index, valid, num_groups, m = sc_oracle.group_layout(groups, 6)
+  assert (t.num_groups, t.m, t.slots) == (num_groups, m, num_groups * m)
+  assert np.array_equal(t.valid.numpy().astype(bool), valid.numpy())
+  assert np.array_equal(t.index.numpy()[valid.numpy()],
+                        gather_index.numpy()[valid.numpy()])
+  # CSR inverse: every valid slot appears once, under its atom, ascending
+  ptr, slots = t.atom_ptr.numpy(), t.atom_slots.numpy()
+  seen = []
+  for atom in range(6):
+    mine = slots[ptr[atom]: ptr[atom + 1]]
+    assert list(mine) == sorted(mine)
+    for slot in mine:
+      assert t.index.numpy()[slot] == atom and t.valid.numpy()[slot]
+      seen.append(slot)
+  assert sorted(seen) == list(np.nonzero(valid.numpy())[0])
+  with pytest.raises(IndexError):
+    group_tables.GroupTables([[0, 9]], 6, torch.device('cpu'))
+
+
+def test_conv_geometry_helpers():
+  from utils import convolutions
+  for img, k, st in ((256, 11, 1), (30, 8, 4), (32, 16, 8), (16, 8, 4)):
+    assert convolutions.get_padding_amt(img, k, st) == (
+        sc_oracle.conv_padding_amount(img, k, st))
+    lead, trail = convolutions.get_padding_amt(img, k, st)
+    padded = img + lead + trail
+    assert convolutions.code_dim_from_padded_img_dim(padded, k, st) == (
+        sc_oracle.conv_code_dim(padded, k, st))
+  imgs = torch.zeros(2, 1, 20, 24)
+  pad = ((3, 4), (2, 5))
+  assert torch.equal(convolutions.create_mask(imgs, pad),
+                     sc_oracle.conv_mask(imgs, pad))
+  assert torch.equal(convolutions.create_mask(imgs, None),
+                     torch.ones_like(imgs))
+  g = convolutions.geometry(imgs, torch.zeros(5, 1, 4, 4), (2, 2), pad)
+  assert (g.b, g.c, g.h, g.w, g.s, g.kh, g.kw) == (2, 1, 20, 24, 5, 4, 4)
+  assert (g.pad_lead_v, g.pad_trail_v, g.pad_lead_h, g.pad_trail_h) == (
+      3, 4, 2, 5)
+
+
+def test_trainer_rejects_out_of_scope_features_and_bad_names():
+  import vtc_hip
+  from training import sparse_coding
+  D = torch.eye(4)
+  base = {'mode': 'fully-connected', 'num_epochs': 1,
+          'code_inference_algorithm': 'fista',
+          'inference_param_schedule': {0: {'sparsity_weight': 0.1,
+                                           'num_iters': 2}},
+          'dictionary_update_algorithm': 'sc_steepest_descent',
+          'dict_update_param_schedule': {0: {'stepsize': 0.1,
+                                             'num_iters': 1}}}
+  with pytest.raises(NotImplementedError):
+    sparse_coding.train_dictionary(
+        [], [], D, dict(base, training_visualization_schedule={0}))
+  with pytest.raises(AssertionError):
+    sparse_coding.train_dictionary(
+        [], [], D, dict(base, inference_param_schedule={1: {}}))
+  with pytest.raises(vtc_hip.VtcHipError):   # CPU dictionary: no fallback
+    sparse_coding.train_dictionary([], [], D, base)
+  with pytest.raises(KeyError):
+    sparse_coding._load_plugins('convolutional', 'subspace_fista',
+                                'sc_steepest_descent')
+  with pytest.raises(ImportError):
+    # the reference's tree lacks this module too (sparse_coding.py:423-424)
+    sparse_coding._load_plugins('fully-connected', 'fista',
+                                'subspace_sc_steepest_descent')
+
+
+# ---------------------------------------------------------------- 2 ranks
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, out_dir):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..',
+                                  'vision-transform-codes_amd'))
+  sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+  from vtc_hip import parallel
+  import sc_oracle as oracle
+  torch.set_num_threads(2)
+  parallel.enable()
+  assert parallel.world_size() == world and parallel.rank() == rank
+  X = torch.from_numpy(helpers.gaussian_patches(7, 64, 32))
+  D = torch.from_numpy(helpers.unit_rows(8, 48, 32))
+  C = oracle.fc_ista_fista(X, D, 0.05, 10)
+  shard = slice(rank * 32, rank * 32 + 32)
+  Xs, Cs = X[shard], C[shard]
+  # local un-normalised partials, exactly what the HIP gradient entry returns
+  grad_sum = torch.mm(Cs.t(), torch.mm(Cs, D) - Xs)
+  energy = (Cs * Cs).sum(0)
+  parallel.all_reduce_sum_(grad_sum, energy)      # packed: one collective
+  total = parallel.global_batch(Xs.shape[0], X.device)
+  assert total == 64
+  parallel.enable(equal_shards=False)
+  assert parallel.global_batch(Xs.shape[0] - rank, X.device) == 63
+  Dn = D.clone()
+  Dn.sub_(0.1 * (grad_sum / total))
+  Dn.div_(Dn.norm(p=2, dim=1)[:, None])
+  torch.save({'dict': Dn, 'energy': energy},
+             os.path.join(out_dir, 'rank%d.pt' % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_data_parallel_update_matches_single_process(tmp_path):
+  """Shard a batch over 2 gloo ranks: summed shard gradients / global batch
+  reproduce the full-batch update, and both ranks end bit-identical."""
+  world = 2
+  mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)),
+           nprocs=world, join=True)
+  r0 = torch.load(tmp_path / 'rank0.pt', weights_only=True)
+  r1 = torch.load(tmp_path / 'rank1.pt', weights_only=True)
+  assert torch.equal(r0['dict'], r1['dict'])
+  assert torch.equal(r0['energy'], r1['energy'])
+  X = torch.from_numpy(helpers.gaussian_patches(7, 64, 32))
+  D = torch.from_numpy(helpers.unit_rows(8, 48, 32))
+  C = sc_oracle.fc_ista_fista(X, D, 0.05, 10)
+  full = D.clone()
+  sc_oracle.fc_steepest_descent(X, full, C, stepsize=0.1)
+  assert helpers.rel_err(r0['dict'].numpy(), full.numpy()) < 1e-6
+  assert helpers.rel_err(r0['energy'].numpy(), (C * C).sum(0).numpy()) < 1e-6

@@ -1,0 +1,111 @@
+"""Subspace (group-LASSO) inference and update on the GPU vs golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import sc_oracle
+
+pytestmark = pytest.mark.gpu
+
+RAGGED = [[0, 2, 5], [1], [2, 3, 4, 5]]
+GROUPS4 = [list(range(4 * i, 4 * i + 4)) for i in range(16)]
+
+
+@pytest.fixture(scope='module')
+def plugins():
+  from analysis_transforms.fully_connected import subspace_ista_fista
+  from dict_update_rules.fully_connected import (
+      subspace_sc_cheap_quadratic_descent)
+  return subspace_ista_fista, subspace_sc_cheap_quadratic_descent
+
+
+def test_ragged_overlapping_groups(device, plugins):
+  sub = plugins[0]
+  g = helpers.load('subspace')
+  X = helpers.to_dev(g['ro_images'], device)
+  D = helpers.to_dev(g['ro_dictionary'], device)
+  for variant in ('ista', 'fista'):
+    codes = sub.run(X, D, RAGGED, 0.02, 30, variant=variant)
+    helpers.assert_codes_match(codes.cpu().numpy(), g['ro_codes_' + variant],
+                               2e-5, 'ragged ' + variant, max_flip_mag=1e-5)
+  init = helpers.to_dev(g['ro_codes_ista'], device)
+  keep = init.clone()
+  warm = sub.run(X, D, RAGGED, 0.02, 10, initial_codes=init)
+  assert torch.equal(init, keep)
+  helpers.assert_codes_match(warm.cpu().numpy(), g['ro_codes_warm'], 2e-5,
+                             'ragged warm', max_flip_mag=1e-5)
+
+
+def test_groups_of_four_and_mini_c4(device, plugins):
+  sub = plugins[0]
+  g = helpers.load('subspace')
+  X = helpers.to_dev(g['g4_images'], device)
+  D = helpers.to_dev(g['g4_dictionary'], device)
+  codes = sub.run(X, D, GROUPS4, 0.02, 40)
+  helpers.assert_codes_match(codes.cpu().numpy(), g['g4_codes_fista'], 2e-5,
+                             'groups of 4', max_flip_mag=1e-5)
+  X = helpers.to_dev(helpers.gaussian_patches(24, 32, 256), device)
+  D = helpers.to_dev(helpers.unit_rows(25, 512, 256), device)
+  groups = [list(map(int, x)) for x in np.array_split(np.arange(512), 64)]
+  codes = sub.run(X, D, groups, 0.008, 50)
+  helpers.assert_codes_match(codes.cpu().numpy(), g['c4_codes_fista'], 2e-5,
+                             'mini config 4', max_flip_mag=1e-5)
+
+
+def test_early_stopping_and_unsupported_options(device, plugins):
+  sub = plugins[0]
+  g = helpers.load('subspace')
+  X = helpers.to_dev(g['g4_images'], device)
+  D = helpers.to_dev(g['g4_dictionary'], device)
+  Xc, Dc = torch.from_numpy(g['g4_images']), torch.from_numpy(
+      g['g4_dictionary'])
+  ref = sc_oracle.subspace_ista_fista(Xc, Dc, GROUPS4, 0.02, 400,
+                                      variant='ista',
+                                      early_stopping_epsilon=5e-3)
+  codes = sub.run(X, D, GROUPS4, 0.02, 400, variant='ista',
+                  early_stopping_epsilon=5e-3)
+  assert 1 < sub.run.last_iters < 400
+  helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), 1e-4,
+                             'early stop', max_flip_mag=1e-4)
+  with pytest.raises(NotImplementedError):
+    sub.run(X, D, GROUPS4, 0.02, 5, hard_threshold=True)
+  with pytest.raises(NotImplementedError):
+    sub.run(X, D, GROUPS4, 0.02, 5, ret_summed_gduplicates=False)
+
+
+def test_subspace_cheap_quadratic_update(device, plugins):
+  upd = plugins[1]
+  g = helpers.load('subspace')
+  X = helpers.to_dev(g['g4_images'], device)
+  C = helpers.to_dev(g['g4_codes_fista'], device)
+  h = helpers.to_dev(g['g4_hessian'], device)
+  for name, pen in (('pen0', 0.), ('pen2e-4', 2e-4), ('pen0.05', 0.05)):
+    D = helpers.to_dev(g['g4_dictionary'].copy(), device)
+    assert upd.run(X, D, C, GROUPS4, h, pen, stepsize=0.1) is None
+    assert helpers.rel_err(D.cpu().numpy(),
+                           g['g4_dict_after_' + name]) < helpers.REL_TOL_DICT
+  D = helpers.to_dev((g['g4_dictionary'] * 1.5).copy(), device)
+  upd.run(X, D, C, GROUPS4, h, 0.05, stepsize=0.1, normalize_dictionary=False)
+  assert helpers.rel_err(
+      D.cpu().numpy(), g['g4_dict_after_pen0.05_nonorm']
+  ) < helpers.REL_TOL_DICT
+
+
+def test_alignment_gradient_with_shared_atoms(device, plugins):
+  """Overlapping groups: an atom's penalty gradient is the sum over its
+  groups (subspace_sc_cheap_quadratic_descent.py:65-69)."""
+  upd = plugins[1]
+  rs = np.random.RandomState(3)
+  Xn = helpers.gaussian_patches(60, 16, 16)
+  Dn = helpers.unit_rows(61, 6, 16)
+  Cn = (0.1 * rs.randn(16, 6)).astype(np.float32)
+  hn = np.abs(rs.randn(6)).astype(np.float32) * 0.01
+  ref = torch.from_numpy(Dn.copy())
+  sc_oracle.subspace_cheap_quadratic_descent(
+      torch.from_numpy(Xn), ref, torch.from_numpy(Cn), RAGGED,
+      torch.from_numpy(hn), 0.05, stepsize=0.05)
+  D = helpers.to_dev(Dn.copy(), device)
+  upd.run(helpers.to_dev(Xn, device), D, helpers.to_dev(Cn, device), RAGGED,
+          helpers.to_dev(hn, device), 0.05, stepsize=0.05)
+  assert helpers.rel_err(D.cpu().numpy(), ref.numpy()) < helpers.REL_TOL_DICT

@@ -1,0 +1,87 @@
+"""The per-batch training step on the GPU against trajectories recorded from
+the reference's own train_dictionary."""
+import pathlib
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _fc_params():
+  return {
+      'mode': 'fully-connected', 'num_epochs': 1,
+      'code_inference_algorithm': 'fista',
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.02, 'num_iters': 15},
+          2: {'sparsity_weight': 0.01, 'num_iters': 30}},
+      'dictionary_update_algorithm': 'sc_cheap_quadratic_descent',
+      'dict_update_param_schedule': {
+          0: {'stepsize': 0.1, 'num_iters': 1},
+          2: {'stepsize': 0.05, 'num_iters': 2}}}
+
+
+def test_fc_trajectory(device, tmp_path):
+  from training import sparse_coding
+  g = helpers.load('trainer')
+  X = helpers.to_dev(g['fc_images'], device)
+  for steps in (1, 2, 3):
+    D = helpers.to_dev(g['fc_dictionary0'].copy(), device)
+    batches = [X[32 * i: 32 * i + 32] for i in range(steps)]
+    params = _fc_params()
+    if steps == 3:
+      params['checkpoint_schedule'] = {0, 2}
+      params['logging_folder_fullpath'] = pathlib.Path(tmp_path)
+    state = sparse_coding.train_dictionary(batches, batches, D, params)
+    assert helpers.rel_err(D.cpu().numpy(),
+                           g['fc_dict_after_step%d' % steps]) < 2e-5
+  assert helpers.rel_err(state.hessian_diag.cpu().numpy(),
+                         g['fc_hessian_after_step3']) < 2e-5
+  # checkpoints are plain pickled numpy arrays, the reference's format
+  with open(tmp_path / 'checkpoint_dictionary_iter_0', 'rb') as f:
+    first = pickle.load(f)
+  assert np.array_equal(first, g['fc_dictionary0'])
+  assert (tmp_path / 'checkpoint_dictionary_iter_2').exists()
+
+
+def test_conv_trajectory(device):
+  from training import sparse_coding
+  g = helpers.load('trainer')
+  imgs = helpers.to_dev(g['conv_images_padded'], device)
+  pad = tuple(tuple(int(v) for v in row) for row in g['conv_padding'])
+  params = {
+      'mode': 'convolutional', 'num_epochs': 1,
+      'code_inference_algorithm': 'ista', 'strides': (4, 4), 'padding': pad,
+      'inference_param_schedule': {0: {'sparsity_weight': 0.05,
+                                       'num_iters': 8}},
+      'dictionary_update_algorithm': 'sc_cheap_quadratic_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.005, 'num_iters': 1}}}
+  for steps in (1, 3):
+    K = helpers.to_dev(g['conv_dictionary0'].copy(), device)
+    batches = [imgs[2 * i: 2 * i + 2] for i in range(steps)]
+    sparse_coding.train_dictionary(batches, batches, K, params)
+    assert helpers.rel_err(K.cpu().numpy(),
+                           g['conv_dict_after_step%d' % steps]) < 2e-5
+
+
+def test_subspace_step_runs_and_keeps_unit_norm(device):
+  from training import sparse_coding
+  X = helpers.to_dev(helpers.gaussian_patches(80, 64, 64), device)
+  D = helpers.to_dev(helpers.unit_rows(81, 32, 64), device)
+  params = {
+      'mode': 'fully-connected', 'num_epochs': 2,
+      'code_inference_algorithm': 'subspace_fista',
+      'group_assignments': [list(range(4 * i, 4 * i + 4)) for i in range(8)],
+      'subspace_alignment_penalty': 2e-4,
+      'inference_param_schedule': {0: {'sparsity_weight': 0.02,
+                                       'num_iters': 10}},
+      'dictionary_update_algorithm': 'subspace_sc_cheap_quadratic_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.05, 'num_iters': 1}}}
+  before = D.clone()
+  sparse_coding.train_dictionary([X[:32], X[32:]], [], D, params)
+  assert not torch.allclose(D, before)
+  assert np.allclose(D.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)

@@ -1,0 +1,104 @@
+"""
+ISTA / FISTA sparse inference for fully-connected dictionaries on MI355X.
+
+Drop-in for the reference plugin of the same import path
+(vision_transform_codes/analysis_transforms/fully_connected/ista_fista.py:14-148):
+same `run` signature, keyword names, return value and non-mutation guarantees.
+The arithmetic runs in libvtc_hip.so (vtc_fc_ista_fista): per iteration the two
+contractions Y D - X and (.) D^T on the matrix cores with the shrinkage and the
+FISTA extrapolation fused into the second contraction's epilogue.
+"""
+import ctypes
+
+import torch
+
+import vtc_hip
+
+
+def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
+        initial_codes=None, early_stopping_epsilon=None,
+        nonnegative_only=False, hard_threshold=False, precision=None,
+        stepsize=None):
+  """
+  Infers sparse codes for a batch of flattened image patches.
+
+  Parameters
+  ----------
+  images : torch.Tensor(float32, size=(b, n)) on a HIP device
+  dictionary : torch.Tensor(float32, size=(s, n)), rows are basis functions
+  sparsity_weight : float or 0-d tensor, the lambda of the LASSO objective
+  num_iters : int, number of ISTA/FISTA steps (>= 1)
+  variant : 'ista' or 'fista'
+  initial_codes : torch.Tensor(float32, size=(b, s)), optional warm start;
+      never written
+  early_stopping_epsilon : float, optional.  Stop once the mean absolute code
+      change per component, divided by the stepsize, drops below this (checked
+      after every iteration but the first; costs a host sync per iteration).
+  nonnegative_only, hard_threshold : bool, choose among the four thresholding
+      functions of the reference (ista_fista.py:107-120)
+  precision : None | 'f32' | 'bf16x3' | 'bf16' -- extension, see
+      vtc_hip.set_default_precision.  None uses the process-wide default.
+  stepsize : float, optional -- extension: skip the Lipschitz eigen-solve and
+      use this eta (tests inject the eta of a golden vector this way).
+
+  Returns
+  -------
+  codes : torch.Tensor(float32, size=(b, s)), freshly allocated
+  """
+  assert variant in ['ista', 'fista']
+  lib = vtc_hip.load_library()
+  images = vtc_hip.require_device_tensor(images, 'images').contiguous()
+  dictionary = vtc_hip.require_device_tensor(
+      dictionary, 'dictionary').contiguous()
+  b, n = images.shape
+  s = dictionary.shape[0]
+  assert dictionary.shape[1] == n
+  if initial_codes is not None:
+    initial_codes = vtc_hip.require_device_tensor(
+        initial_codes, 'initial_codes').contiguous()
+    assert tuple(initial_codes.shape) == (b, s)
+  if num_iters < 1:
+    # the reference leaves `codes` unbound in this case
+    raise UnboundLocalError(
+        "local variable 'codes' referenced before assignment")
+
+  if stepsize is None:
+    # largest eigenvalue of D^T D (n x n), as ista_fista.py:72-80
+    stepsize = vtc_hip.stepsize_from_gram(
+        vtc_hip.gram(dictionary, transpose_a=True), dictionary)
+  eta = float(stepsize)
+  lam = float(sparsity_weight)
+
+  mode = vtc_hip.threshold_mode(nonnegative_only, hard_threshold)
+  prec = _resolve_precision(precision, b, n, s, early_stopping_epsilon)
+  ws_bytes = lib.vtc_fc_ista_fista_workspace_bytes(b, n, s, prec)
+  ws = vtc_hip.workspace(ws_bytes, images.device)
+  codes = torch.empty((b, s), dtype=torch.float32, device=images.device)
+  iters_run = ctypes.c_int(0)
+  eps = -1.0 if early_stopping_epsilon is None else float(
+      early_stopping_epsilon)
+  vtc_hip.check(lib.vtc_fc_ista_fista(
+      vtc_hip.ptr(images), vtc_hip.ptr(dictionary), vtc_hip.ptr(initial_codes),
+      vtc_hip.ptr(codes), b, n, s, eta, lam, int(num_iters),
+      vtc_hip.variant_code(variant), mode, eps, prec, vtc_hip.ptr(ws),
+      ws.numel(), ctypes.byref(iters_run),
+      vtc_hip.current_stream(images.device)), 'vtc_fc_ista_fista')
+  run.last_iters = iters_run.value
+  return codes
+
+
+def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
+  name = precision if precision is not None else (
+      vtc_hip.get_default_precision())
+  if name == 'auto':
+    fused_ok = (early_stopping_epsilon is None and n == 256 and
+                s % 128 == 0 and fused_available())
+    return vtc_hip.BF16X3 if fused_ok else vtc_hip.F32
+  return vtc_hip.PRECISIONS[name]
+
+
+def fused_available():
+  """True when libvtc_hip was built with the fused bf16 FISTA kernel."""
+  lib = vtc_hip.load_library()
+  return lib.vtc_fc_ista_fista_workspace_bytes(32, 256, 1024,
+                                               vtc_hip.BF16X3) > 256

@@ -1,0 +1,189 @@
+// Fully-connected ISTA/FISTA, general exact-f32 path (any b, n, s; all four
+// thresholds; warm start; early stopping).
+//
+// Follows analysis_transforms/fully_connected/ista_fista.py:100-146 of the
+// reference: per iteration
+//     R = Y D - X                      (kernel 1, epilogue subtracts X)
+//     C = shrink(Y - eta * (R D^T))    (kernel 2, the whole proximal step and
+//     Y = C + beta (C - C_prev)         the FISTA extrapolation live in its
+//     C_prev = C                        epilogue: no elementwise passes)
+// The reference's formulation is kept (residual form, eta*g rounded before the
+// subtraction, beta rounded to f32 before the multiply) so that differences
+// stay at f32 summation-order level.
+#include "common.h"
+#include "gemm_f32.h"
+#include "fc_fused.h"
+
+#include <math.h>
+#include <vector>
+
+namespace vtc {
+
+struct EpiProx {
+  float* Y;        // gradient evaluation points, updated in place
+  float* C;        // codes of the previous iteration in, new codes out
+  int64_t ld;
+  float eta, cutoff, beta;
+  int mode;        // vtc_threshold
+  int fista;       // 0: Y and C are the same buffer
+  double* delta_sum;  // sum |C - C_prev| / eta, or nullptr
+  double local;
+
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float g,
+                                             int) {
+    const int64_t i = row * ld + col;
+    const float y = Y[i];
+    const float c = shrink(sub_rn(y, mul_rn(eta, g)), cutoff, mode);
+    float d;
+    if (fista) {
+      d = sub_rn(c, C[i]);
+      Y[i] = add_rn(c, mul_rn(beta, d));
+    } else {
+      d = sub_rn(c, y);
+    }
+    C[i] = c;
+    if (delta_sum) local += (double)(fabsf(d) / eta);
+  }
+  __device__ __forceinline__ void block_end() {
+    if (!delta_sum) return;
+    const double w = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) atomicAdd(delta_sum, w);
+  }
+};
+
+void fista_betas(int num_iters, std::vector<float>* out) {
+  // ista_fista.py:123-125, Python float64 arithmetic; the product
+  // beta * (codes - old) rounds beta to f32 first.
+  out->resize(num_iters);
+  double t = 1.0;
+  for (int k = 0; k < num_iters; ++k) {
+    const double t_next = (1.0 + sqrt(1.0 + 4.0 * t * t)) / 2.0;
+    (*out)[k] = (float)((t - 1.0) / t_next);
+    t = t_next;
+  }
+}
+
+struct GenericLayout {
+  size_t y_elems, r_elems;
+};
+
+static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
+  size_t bytes = 0;
+  bytes += align_up((size_t)b * s * sizeof(float), 256);  // Y
+  bytes += align_up((size_t)b * n * sizeof(float), 256);  // R
+  bytes += 256;                                           // stop accumulator
+  return bytes;
+}
+
+static int run_generic_f32(const float* images, const float* dictionary,
+                           const float* initial_codes, float* codes, int64_t b,
+                           int64_t n, int64_t s, float eta, float cutoff,
+                           int num_iters, int variant, int threshold,
+                           float eps, void* workspace, size_t workspace_bytes,
+                           int* iters_run, hipStream_t st) {
+  if (workspace_bytes < generic_workspace_bytes(b, n, s) || !workspace) {
+    set_error("vtc_fc_ista_fista: workspace too small (%zu < %zu)",
+              workspace_bytes, generic_workspace_bytes(b, n, s));
+    return VTC_ERR_WORKSPACE;
+  }
+  Carver ws(workspace);
+  float* Ybuf = ws.take<float>((size_t)b * s);
+  float* R = ws.take<float>((size_t)b * n);
+  double* delta_sum = ws.take<double>(1);
+
+  const bool fista = (variant == VTC_FISTA);
+  float* Y = fista ? Ybuf : codes;  // ISTA evaluates the gradient at the codes
+  const size_t code_bytes = (size_t)b * s * sizeof(float);
+  if (initial_codes) {
+    VTC_HIP_CHECK(hipMemcpyAsync(codes, initial_codes, code_bytes,
+                                 hipMemcpyDeviceToDevice, st));
+    if (fista)
+      VTC_HIP_CHECK(hipMemcpyAsync(Y, initial_codes, code_bytes,
+                                   hipMemcpyDeviceToDevice, st));
+  } else {
+    VTC_HIP_CHECK(hipMemsetAsync(codes, 0, code_bytes, st));
+    if (fista) VTC_HIP_CHECK(hipMemsetAsync(Y, 0, code_bytes, st));
+  }
+
+  std::vector<float> betas;
+  fista_betas(num_iters, &betas);
+  int done = 0;
+  for (int k = 0; k < num_iters; ++k) {
+    // R = Y D - X : A = Y (b,s) k-contiguous, B = D (s,n) = [K][N]
+    EpiMinus e1{R, images, n, n};
+    int rc = launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1, e1,
+                                          st);
+    if (rc != VTC_OK) return rc;
+    if (eps >= 0.f)
+      VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
+    // G = R D^T : A = R (b,n) k-contiguous, B = D (s,n) = [N][K]
+    EpiProx e2{Y, codes, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
+               fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0};
+    rc = launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1, e2, st);
+    if (rc != VTC_OK) return rc;
+    done = k + 1;
+    if (eps >= 0.f) {
+      double total = 0.0;
+      VTC_HIP_CHECK(hipMemcpyAsync(&total, delta_sum, sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+      VTC_HIP_CHECK(hipStreamSynchronize(st));
+      const float mean = (float)(total / ((double)b * (double)s));
+      if (mean < eps && k > 0) break;  // ista_fista.py:143-144
+    }
+  }
+  if (iters_run) *iters_run = done;
+  return VTC_OK;
+}
+
+}  // namespace vtc
+
+using namespace vtc;
+
+extern "C" size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n,
+                                                    int64_t s,
+                                                    int precision) {
+  if (b <= 0 || n <= 0 || s <= 0) return 256;
+  if (precision == VTC_F32) return generic_workspace_bytes(b, n, s);
+  return fused_workspace_bytes(b, n, s, precision);
+}
+
+extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
+                                 const float* initial_codes, float* codes,
+                                 int64_t b, int64_t n, int64_t s,
+                                 float stepsize, float sparsity_weight,
+                                 int num_iters, int variant, int threshold,
+                                 float early_stopping_epsilon, int precision,
+                                 void* workspace, size_t workspace_bytes,
+                                 int* iters_run, void* stream) {
+  VTC_REQUIRE(images && dictionary && codes, "vtc_fc_ista_fista: null pointer");
+  VTC_REQUIRE(b >= 0 && n > 0 && s > 0, "vtc_fc_ista_fista: bad sizes");
+  VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
+              "vtc_fc_ista_fista: variant must be ista or fista");
+  VTC_REQUIRE(threshold >= VTC_SOFT && threshold <= VTC_HARD_NONNEG,
+              "vtc_fc_ista_fista: unknown threshold mode %d", threshold);
+  VTC_REQUIRE(num_iters >= 1,
+              "vtc_fc_ista_fista: num_iters must be >= 1 (the reference "
+              "leaves `codes` unbound for 0)");
+  VTC_REQUIRE(precision >= VTC_F32 && precision <= VTC_BF16,
+              "vtc_fc_ista_fista: unknown precision %d", precision);
+  if (iters_run) *iters_run = 0;
+  if (b == 0) return VTC_OK;
+  // lambda*eta: the Python float is rounded to f32, then one f32 multiply
+  const float cutoff = sparsity_weight * stepsize;
+  hipStream_t st = as_stream(stream);
+  if (precision != VTC_F32) {
+    if (early_stopping_epsilon >= 0.f ||
+        !fused_shape_supported(b, n, s, precision)) {
+      set_error("vtc_fc_ista_fista: precision %d supports only n == 256, "
+                "s %% 128 == 0 and no early stopping; use VTC_F32", precision);
+      return VTC_ERR_UNSUPPORTED;
+    }
+    return run_fused(images, dictionary, initial_codes, codes, b, n, s,
+                     stepsize, cutoff, num_iters, variant, threshold,
+                     precision, workspace, workspace_bytes, iters_run, st);
+  }
+  return run_generic_f32(images, dictionary, initial_codes, codes, b, n, s,
+                         stepsize, cutoff, num_iters, variant, threshold,
+                         early_stopping_epsilon, workspace, workspace_bytes,
+                         iters_run, st);
+}

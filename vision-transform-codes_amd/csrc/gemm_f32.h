@@ -1,0 +1,259 @@
+// Exact-f32 tiled contraction on the gfx950 matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 takes f32 operands and accumulates in f32: per output
+// element the result is a k-ordered fmaf chain, i.e. the same arithmetic class
+// as the reference's torch.mm in float32.  This is the "parity" contraction
+// every plugin can fall back to for any shape; the bf16 kernels in
+// fc_fista_fused.hip are the fast path for the headline shape.
+//
+// Block = 256 threads = 4 waves in a 2x2 arrangement, block tile 128x128,
+// wave tile 64x64 (2x2 MFMA tiles, 64 accumulator VGPRs), K step 16.
+// Operands are staged k-major in LDS ([k][row], pitch 132 floats) so that the
+// 32 lanes of a half-wave read 32 consecutive dwords: conflict-free
+// ds_read_b32 for both A (lane -> row) and B (lane -> column).
+#pragma once
+
+#include "common.h"
+
+namespace vtc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kGemmBM = 128;
+constexpr int kGemmBN = 128;
+constexpr int kGemmBK = 16;
+constexpr int kGemmPitch = 132;
+constexpr int kGemmThreads = 256;
+
+// C[M,N] = opA * opB over k in [z*k_chunk, min(K, (z+1)*k_chunk)), z=blockIdx.y
+//   A_KC: A is stored [M][K] (k contiguous, leading dim lda); else [K][M].
+//   B_KC: B is stored [N][K] (k contiguous, leading dim ldb); else [K][N].
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  int64_t M, N, K;
+  int64_t lda, ldb;
+  int64_t k_chunk;   // multiple of kGemmBK
+  int a_vec, b_vec;  // 16-byte vector loads allowed for this operand
+};
+
+__device__ __forceinline__ float4 load4_guarded(const float* p, int64_t avail,
+                                                bool line_ok, bool vec_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!line_ok || avail <= 0) return v;
+  if (vec_ok && avail >= 4) return *reinterpret_cast<const float4*>(p);
+  v.x = p[0];
+  if (avail > 1) v.y = p[1];
+  if (avail > 2) v.z = p[2];
+  if (avail > 3) v.w = p[3];
+  return v;
+}
+
+// Stage one 128 x 16 operand tile (global -> registers).
+//   K_CONTIG : element (line, k) at P[line*ld + k]
+//   !K_CONTIG: element (line, k) at P[k*ld + line]
+template <bool K_CONTIG>
+__device__ __forceinline__ void stage_load(const float* P, int64_t ld,
+                                           int64_t line0, int64_t lines,
+                                           int64_t k0, int64_t k_end,
+                                           bool vec_ok, int tid,
+                                           float4 (&regs)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * kGemmThreads;
+    if (K_CONTIG) {
+      const int line = f >> 2, kq = f & 3;
+      const int64_t gl = line0 + line, gk = k0 + kq * 4;
+      regs[i] = load4_guarded(P + gl * ld + gk, k_end - gk, gl < lines, vec_ok);
+    } else {
+      const int kr = f >> 5, lq = f & 31;
+      const int64_t gk = k0 + kr, gl = line0 + lq * 4;
+      regs[i] = load4_guarded(P + gk * ld + gl, lines - gl, gk < k_end, vec_ok);
+    }
+  }
+}
+
+template <bool K_CONTIG>
+__device__ __forceinline__ void stage_store(float (*S)[kGemmPitch], int tid,
+                                            const float4 (&regs)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * kGemmThreads;
+    if (K_CONTIG) {
+      const int line = f >> 2, kq = f & 3;
+      S[kq * 4 + 0][line] = regs[i].x;
+      S[kq * 4 + 1][line] = regs[i].y;
+      S[kq * 4 + 2][line] = regs[i].z;
+      S[kq * 4 + 3][line] = regs[i].w;
+    } else {
+      const int kr = f >> 5, lq = f & 31;
+      *reinterpret_cast<float4*>(&S[kr][lq * 4]) = regs[i];
+    }
+  }
+}
+
+template <bool A_KC, bool B_KC, class Epi>
+__global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
+                                                                Epi epi) {
+  __shared__ __attribute__((aligned(16))) float As[2][kGemmBK][kGemmPitch];
+  __shared__ __attribute__((aligned(16))) float Bs[2][kGemmBK][kGemmPitch];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t tiles_n = (g.N + kGemmBN - 1) / kGemmBN;
+  const int64_t tile = blockIdx.x;
+  const int64_t m0 = (tile / tiles_n) * kGemmBM;
+  const int64_t n0 = (tile % tiles_n) * kGemmBN;
+  const int z = blockIdx.y;
+  const int64_t k_begin = (int64_t)z * g.k_chunk;
+  const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
+  const int nk = (int)((k_end - k_begin + kGemmBK - 1) / kGemmBK);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rb[2];
+  if (nk > 0) {
+    stage_load<A_KC>(g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid, ra);
+    stage_load<B_KC>(g.B, g.ldb, n0, g.N, k_begin, k_end, g.b_vec, tid, rb);
+    stage_store<A_KC>(As[0], tid, ra);
+    stage_store<B_KC>(Bs[0], tid, rb);
+  }
+  __syncthreads();
+
+  const int half = lane >> 5, l31 = lane & 31;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      const int64_t k0 = k_begin + (int64_t)(kt + 1) * kGemmBK;
+      stage_load<A_KC>(g.A, g.lda, m0, g.M, k0, k_end, g.a_vec, tid, ra);
+      stage_load<B_KC>(g.B, g.ldb, n0, g.N, k0, k_end, g.b_vec, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < kGemmBK / 2; ++kk) {
+      const int k = kk * 2 + half;
+      const float a0 = As[cur][k][wm * 64 + l31];
+      const float a1 = As[cur][k][wm * 64 + 32 + l31];
+      const float b0 = Bs[cur][k][wn * 64 + l31];
+      const float b1 = Bs[cur][k][wn * 64 + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      stage_store<A_KC>(As[cur ^ 1], tid, ra);
+      stage_store<B_KC>(Bs[cur ^ 1], tid, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // C/D layout of the 32x32 MFMA: column = lane & 31,
+  // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int64_t col = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row =
+            m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], z);
+      }
+    }
+  }
+  epi.block_end();
+}
+
+static inline int gemm_vec_ok(const float* p, int64_t ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0) ? 1 : 0;
+}
+
+// k_slices > 1 => split-K, the epilogue receives the slice index.
+template <bool A_KC, bool B_KC, class Epi>
+static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
+                           int64_t ldb, int64_t M, int64_t N, int64_t K,
+                           int k_slices, Epi epi, hipStream_t st) {
+  if (M <= 0 || N <= 0) return VTC_OK;
+  GemmArgs g;
+  g.A = A;
+  g.B = B;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  if (k_slices < 1) k_slices = 1;
+  int64_t chunk = ceil_div(ceil_div(K, k_slices), kGemmBK) * kGemmBK;
+  if (chunk < kGemmBK) chunk = kGemmBK;
+  g.k_chunk = chunk;
+  g.a_vec = gemm_vec_ok(A, lda);
+  g.b_vec = gemm_vec_ok(B, ldb);
+  const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
+  if (tiles > 0x7fffffffLL) {
+    set_error("gemm: too many tiles (%lld)", (long long)tiles);
+    return VTC_ERR_INVALID_ARGUMENT;
+  }
+  dim3 grid((unsigned)tiles, (unsigned)k_slices, 1);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, Epi>), grid,
+                     dim3(kGemmThreads), 0, st, g, epi);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+// Number of K slices actually covered by launch_gemm_f32 for (K, k_slices).
+static inline int gemm_effective_slices(int64_t K, int k_slices) {
+  if (k_slices < 1) k_slices = 1;
+  int64_t chunk = ceil_div(ceil_div(K, k_slices), kGemmBK) * kGemmBK;
+  if (chunk < kGemmBK) chunk = kGemmBK;
+  return (int)ceil_div(K > 0 ? K : 1, chunk);
+}
+
+// ---- epilogues shared by several translation units -----------------------
+struct EpiStore {  // C = acc
+  float* C;
+  int64_t ldc;
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
+                                             int) const {
+    C[row * ldc + col] = v;
+  }
+  __device__ __forceinline__ void block_end() const {}
+};
+
+struct EpiSlab {  // split-K partial: slab z
+  float* slabs;
+  int64_t slab_stride, ldc;
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
+                                             int z) const {
+    slabs[(int64_t)z * slab_stride + row * ldc + col] = v;
+  }
+  __device__ __forceinline__ void block_end() const {}
+};
+
+struct EpiMinus {  // C = acc - X   (the reconstruction residual)
+  float* C;
+  const float* X;
+  int64_t ldc, ldx;
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
+                                             int) const {
+    C[row * ldc + col] = sub_rn(v, X[row * ldx + col]);
+  }
+  __device__ __forceinline__ void block_end() const {}
+};
+
+// out[i] = sum_z slabs[z][i], z ascending: a fixed order, so the result does
+// not depend on scheduling (bitwise reproducible run to run).
+int launch_slab_reduce(const float* slabs, int slices, int64_t count,
+                       float* out, hipStream_t st);
+
+}  // namespace vtc

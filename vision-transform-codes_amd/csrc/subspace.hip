@@ -1,0 +1,248 @@
+// Subspace (group-LASSO) ISTA/FISTA and the padded-group index kernels.
+//
+// Restates analysis_transforms/fully_connected/subspace_ista_fista.py:94-190.
+// The reference rearranges codes into a zero-padded (b, G, m) tensor and the
+// dictionary into a (G*m, n) matrix with duplicated rows for atoms that sit in
+// several groups; the same layout is used here, so the two contractions are
+// the fully-connected ones on G*m "slots".  Per iteration:
+//     R = Y Dg - X                               exact-f32 MFMA
+//     P = Y - eta * (R Dg^T)                     epilogue, in place over Y
+//     C = P * max(1 - lambda*eta / ||P_group||, 0);  Y = C + beta (C - C_prev)
+//                                                one pass, a thread per
+//                                                (patch, group)
+#include "common.h"
+#include "gemm_f32.h"
+#include "fc_fused.h"
+
+#include <vector>
+
+namespace vtc {
+
+struct EpiGradStep {  // Y <- Y - eta * g
+  float* Y;
+  int64_t ld;
+  float eta;
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float g,
+                                             int) const {
+    const int64_t i = row * ld + col;
+    Y[i] = sub_rn(Y[i], mul_rn(eta, g));
+  }
+  __device__ __forceinline__ void block_end() const {}
+};
+
+__global__ void gather_rows_kernel(const float* __restrict__ D,
+                                   const int32_t* __restrict__ index,
+                                   const uint8_t* __restrict__ valid,
+                                   float* __restrict__ out, int64_t slots,
+                                   int64_t n) {
+  const int64_t t = blockIdx.x;
+  if (t >= slots) return;
+  const bool ok = valid[t] != 0;
+  const float* src = D + (int64_t)index[t] * n;
+  for (int64_t c = threadIdx.x; c < n; c += blockDim.x)
+    out[t * n + c] = ok ? src[c] : 0.f;
+}
+
+__global__ void gather_cols_kernel(const float* __restrict__ codes,
+                                   const int32_t* __restrict__ index,
+                                   const uint8_t* __restrict__ valid,
+                                   float* __restrict__ out, int64_t b,
+                                   int64_t s, int64_t slots) {
+  const int64_t total = b * slots;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += stride) {
+    const int64_t r = i / slots, t = i % slots;
+    out[i] = valid[t] ? codes[r * s + index[t]] : 0.f;
+  }
+}
+
+__global__ void scatter_add_kernel(const float* __restrict__ grouped,
+                                   const int32_t* __restrict__ atom_ptr,
+                                   const int32_t* __restrict__ atom_slots,
+                                   float* __restrict__ codes, int64_t b,
+                                   int64_t s, int64_t slots) {
+  const int64_t total = b * s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += stride) {
+    const int64_t r = i / s, a = i % s;
+    float acc = 0.f;
+    for (int t = atom_ptr[a]; t < atom_ptr[a + 1]; ++t)
+      acc = add_rn(acc, grouped[r * slots + atom_slots[t]]);
+    codes[i] = acc;
+  }
+}
+
+// One thread per (patch, group): norm over the m slots, shrink, extrapolate.
+__global__ __launch_bounds__(256) void group_prox_kernel(
+    float* __restrict__ Y, float* __restrict__ C, int64_t b, int64_t groups,
+    int m, float cutoff, float beta, int fista, float eta,
+    double* __restrict__ delta_sum) {
+  const int64_t total = b * groups;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double local = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += stride) {
+    float* y = Y + i * m;
+    float* c = C + i * m;
+    float sumsq = 0.f;
+    for (int j = 0; j < m; ++j) sumsq = fmaf(y[j], y[j], sumsq);
+    float norm = sqrtf(sumsq);
+    if (norm == 0.f) norm = 1.f;  // subspace_ista_fista.py:150
+    const float scale = clamp_min0(sub_rn(1.f, cutoff / norm));
+    for (int j = 0; j < m; ++j) {
+      const float cn = mul_rn(y[j], scale);
+      const float d = sub_rn(cn, c[j]);
+      y[j] = fista ? add_rn(cn, mul_rn(beta, d)) : cn;
+      c[j] = cn;
+      if (delta_sum) local += (double)(fabsf(d) / eta);
+    }
+  }
+  if (delta_sum) {
+    const double w = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) atomicAdd(delta_sum, w);
+  }
+}
+
+static size_t subspace_ws_bytes(int64_t b, int64_t n, int64_t slots) {
+  return align_up((size_t)b * slots * sizeof(float), 256) +
+         align_up((size_t)b * n * sizeof(float), 256) + 256;
+}
+
+static unsigned flat_grid(int64_t total) {
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace vtc
+
+using namespace vtc;
+
+extern "C" int vtc_group_gather_rows(const float* dictionary,
+                                     const int32_t* index,
+                                     const uint8_t* valid,
+                                     float* grouped_dictionary, int64_t slots,
+                                     int64_t n, void* stream) {
+  VTC_REQUIRE(dictionary && index && valid && grouped_dictionary,
+              "vtc_group_gather_rows: null pointer");
+  VTC_REQUIRE(slots > 0 && n > 0, "vtc_group_gather_rows: bad sizes");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)slots), dim3(256), 0,
+                     as_stream(stream), dictionary, index, valid,
+                     grouped_dictionary, slots, n);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+extern "C" int vtc_group_gather_cols(const float* codes, const int32_t* index,
+                                     const uint8_t* valid,
+                                     float* grouped_codes, int64_t b,
+                                     int64_t s, int64_t slots, void* stream) {
+  VTC_REQUIRE(codes && index && valid && grouped_codes,
+              "vtc_group_gather_cols: null pointer");
+  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_gather_cols: sizes");
+  if (b == 0) return VTC_OK;
+  hipLaunchKernelGGL(gather_cols_kernel, dim3(flat_grid(b * slots)), dim3(256),
+                     0, as_stream(stream), codes, index, valid, grouped_codes,
+                     b, s, slots);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+extern "C" int vtc_group_scatter_add(const float* grouped_codes,
+                                     const int32_t* atom_ptr,
+                                     const int32_t* atom_slots, float* codes,
+                                     int64_t b, int64_t s, int64_t slots,
+                                     void* stream) {
+  VTC_REQUIRE(grouped_codes && atom_ptr && atom_slots && codes,
+              "vtc_group_scatter_add: null pointer");
+  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_scatter_add: sizes");
+  if (b == 0) return VTC_OK;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(flat_grid(b * s)), dim3(256), 0,
+                     as_stream(stream), grouped_codes, atom_ptr, atom_slots,
+                     codes, b, s, slots);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+extern "C" size_t vtc_subspace_ista_fista_workspace_bytes(int64_t b, int64_t n,
+                                                          int64_t groups,
+                                                          int64_t m) {
+  if (b <= 0 || n <= 0 || groups <= 0 || m <= 0) return 256;
+  return subspace_ws_bytes(b, n, groups * m);
+}
+
+extern "C" int vtc_subspace_ista_fista(
+    const float* images, const float* grouped_dictionary,
+    const float* initial_grouped, float* grouped_codes, int64_t b, int64_t n,
+    int64_t groups, int64_t m, float stepsize, float sparsity_weight,
+    int num_iters, int variant, float early_stopping_epsilon, void* workspace,
+    size_t workspace_bytes, int* iters_run, void* stream) {
+  VTC_REQUIRE(images && grouped_dictionary && grouped_codes,
+              "vtc_subspace_ista_fista: null pointer");
+  VTC_REQUIRE(b >= 0 && n > 0 && groups > 0 && m > 0,
+              "vtc_subspace_ista_fista: bad sizes");
+  VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
+              "vtc_subspace_ista_fista: variant must be ista or fista");
+  VTC_REQUIRE(num_iters >= 1, "vtc_subspace_ista_fista: num_iters >= 1");
+  if (iters_run) *iters_run = 0;
+  if (b == 0) return VTC_OK;
+  const int64_t slots = groups * m;
+  if (!workspace || workspace_bytes < subspace_ws_bytes(b, n, slots)) {
+    set_error("vtc_subspace_ista_fista: workspace too small");
+    return VTC_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver ws(workspace);
+  float* Y = ws.take<float>((size_t)b * slots);
+  float* R = ws.take<float>((size_t)b * n);
+  double* delta_sum = ws.take<double>(1);
+  const float eta = stepsize;
+  const float cutoff = sparsity_weight * stepsize;
+  const float eps = early_stopping_epsilon;
+  const bool fista = (variant == VTC_FISTA);
+  const size_t bytes = (size_t)b * slots * sizeof(float);
+  if (initial_grouped) {
+    VTC_HIP_CHECK(hipMemcpyAsync(Y, initial_grouped, bytes,
+                                 hipMemcpyDeviceToDevice, st));
+    VTC_HIP_CHECK(hipMemcpyAsync(grouped_codes, initial_grouped, bytes,
+                                 hipMemcpyDeviceToDevice, st));
+  } else {
+    VTC_HIP_CHECK(hipMemsetAsync(Y, 0, bytes, st));
+    VTC_HIP_CHECK(hipMemsetAsync(grouped_codes, 0, bytes, st));
+  }
+  std::vector<float> betas;
+  fista_betas(num_iters, &betas);
+  int done = 0;
+  for (int k = 0; k < num_iters; ++k) {
+    EpiMinus e1{R, images, n, n};
+    int rc = launch_gemm_f32<true, false>(Y, slots, grouped_dictionary, n, b,
+                                          n, slots, 1, e1, st);
+    if (rc != VTC_OK) return rc;
+    EpiGradStep e2{Y, slots, eta};
+    rc = launch_gemm_f32<true, true>(R, n, grouped_dictionary, n, b, slots, n,
+                                     1, e2, st);
+    if (rc != VTC_OK) return rc;
+    if (eps >= 0.f)
+      VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
+    hipLaunchKernelGGL(group_prox_kernel, dim3(flat_grid(b * groups)),
+                       dim3(256), 0, st, Y, grouped_codes, b, groups, (int)m,
+                       cutoff, fista ? betas[k] : 0.f, fista ? 1 : 0, eta,
+                       eps >= 0.f ? delta_sum : nullptr);
+    VTC_LAUNCH_CHECK();
+    done = k + 1;
+    if (eps >= 0.f) {
+      double total = 0.0;
+      VTC_HIP_CHECK(hipMemcpyAsync(&total, delta_sum, sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+      VTC_HIP_CHECK(hipStreamSynchronize(st));
+      // the reference averages over the padded (b, G, m) tensor
+      const float mean = (float)(total / ((double)b * (double)slots));
+      if (mean < eps && k > 0) break;
+    }
+  }
+  if (iters_run) *iters_run = done;
+  return VTC_OK;
+}

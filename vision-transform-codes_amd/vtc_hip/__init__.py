@@ -1,0 +1,218 @@
+"""
+Host-side binding of libvtc_hip.so (the C ABI declared in include/vtc_hip.h).
+
+PyTorch is used here for what it is good at on ROCm -- device memory, the
+current HIP stream, torch.distributed -- and nothing else: every arithmetic
+step of the plugins goes through the C entry points below, on raw device
+pointers.  There is deliberately no CPU or eager-PyTorch fallback: if the
+library is missing or a tensor is not on the GPU the call raises.
+"""
+import ctypes
+import os
+import pathlib
+
+import torch
+
+_PKG_ROOT = pathlib.Path(__file__).resolve().parent.parent
+LIBRARY_PATH = _PKG_ROOT / 'libvtc_hip.so'
+
+OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = range(5)
+ISTA, FISTA = 0, 1
+SOFT, SOFT_NONNEG, HARD, HARD_NONNEG = range(4)
+F32, BF16X3, BF16 = range(3)
+PRECISIONS = {'f32': F32, 'bf16x3': BF16X3, 'bf16': BF16}
+
+_lib = None
+
+_c_f32p = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int
+_f32 = ctypes.c_float
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+class ConvGeometry(ctypes.Structure):
+  """struct vtc_conv_geometry of include/vtc_hip.h."""
+  _fields_ = [('b', ctypes.c_int64),
+              ('c', ctypes.c_int32), ('h', ctypes.c_int32),
+              ('w', ctypes.c_int32),
+              ('s', ctypes.c_int32), ('kh', ctypes.c_int32),
+              ('kw', ctypes.c_int32),
+              ('stride_v', ctypes.c_int32), ('stride_h', ctypes.c_int32),
+              ('has_padding', ctypes.c_int32),
+              ('pad_lead_v', ctypes.c_int32), ('pad_trail_v', ctypes.c_int32),
+              ('pad_lead_h', ctypes.c_int32), ('pad_trail_h', ctypes.c_int32)]
+
+
+_GEOM_P = ctypes.POINTER(ConvGeometry)
+
+# name -> (restype, argtypes); kept in one table so that the CPU-only test can
+# check that the library exports every symbol the header declares.
+SIGNATURES = {
+    'vtc_version': (ctypes.c_char_p, []),
+    'vtc_last_error': (ctypes.c_char_p, []),
+    'vtc_abi_version': (_i32, []),
+    'vtc_gram': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'vtc_fc_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i32]),
+    'vtc_fc_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
+                                 _f32, _i32, _i32, _i32, _f32, _i32, _vp, _sz,
+                                 ctypes.POINTER(_i32), _vp]),
+    'vtc_group_gather_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    'vtc_group_gather_cols': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                     _vp]),
+    'vtc_group_scatter_add': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                     _vp]),
+    'vtc_subspace_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i64]),
+    'vtc_subspace_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                       _i64, _f32, _f32, _i32, _i32, _f32,
+                                       _vp, _sz, ctypes.POINTER(_i32), _vp]),
+    'vtc_conv_code_dims': (_i32, [_GEOM_P, ctypes.POINTER(ctypes.c_int32),
+                                  ctypes.POINTER(ctypes.c_int32)]),
+    'vtc_conv_ista_fista_workspace_bytes': (_sz, [_GEOM_P]),
+    'vtc_conv_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _f32, _f32,
+                                   _i32, _i32, _i32, _f32, _vp, _sz,
+                                   ctypes.POINTER(_i32), _vp]),
+    'vtc_fc_dict_gradient_workspace_bytes': (_sz, [_i64, _i64, _i64]),
+    'vtc_fc_dict_gradient': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp,
+                                    _sz, _vp]),
+    'vtc_subspace_alignment_gradient_workspace_bytes': (_sz, [_i64, _i64]),
+    'vtc_subspace_alignment_gradient': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp,
+                                               _i64, _i64, _i64, _i64, _i32,
+                                               _vp, _sz, _vp]),
+    'vtc_fc_dict_apply': (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _f32, _f32,
+                                 _i32, _i64, _i64, _vp]),
+    'vtc_conv_dict_gradient_workspace_bytes': (_sz, [_GEOM_P]),
+    'vtc_conv_dict_gradient': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _vp, _sz,
+                                      _vp]),
+    'vtc_conv_dict_apply': (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _i64,
+                                   _i64, _vp, _vp]),
+    'vtc_code_energy_workspace_bytes': (_sz, [_i64, _i64, _i64]),
+    'vtc_code_energy': (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    'vtc_hessian_ema': (_i32, [_vp, _vp, _i64, _i64, _vp]),
+}
+
+
+class VtcHipError(RuntimeError):
+  pass
+
+
+def load_library():
+  """dlopen libvtc_hip.so (built in-tree by __graft_entry__.build() / make)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not LIBRARY_PATH.exists():
+    raise ImportError(
+        'libvtc_hip.so not found at %s -- build it with `make -C %s` '
+        '(hipcc --offload-arch=gfx950).  There is no CPU fallback.'
+        % (LIBRARY_PATH, _PKG_ROOT / 'csrc'))
+  lib = ctypes.CDLL(str(LIBRARY_PATH), mode=os.RTLD_NOW)
+  for name, (restype, argtypes) in SIGNATURES.items():
+    fn = getattr(lib, name)   # AttributeError if the export is missing
+    fn.restype = restype
+    fn.argtypes = argtypes
+  if lib.vtc_abi_version() != 1:
+    raise ImportError('libvtc_hip.so ABI version mismatch')
+  _lib = lib
+  return lib
+
+
+def check(status, what):
+  """Map a vtc_status to the exception type the reference would raise."""
+  if status == OK:
+    return
+  msg = load_library().vtc_last_error().decode('utf-8', 'replace')
+  text = '%s: %s' % (what, msg)
+  if status == ERR_UNSUPPORTED:
+    raise NotImplementedError(text)
+  if status == ERR_INVALID_ARGUMENT:
+    raise ValueError(text)
+  raise VtcHipError(text)
+
+
+def require_device_tensor(t, name, dtype=torch.float32):
+  if not torch.is_tensor(t):
+    raise TypeError('%s must be a torch.Tensor' % name)
+  if not t.is_cuda:
+    raise VtcHipError(
+        '%s lives on %s: the MI355X engine only runs on HIP device tensors '
+        '(no CPU path is provided on purpose)' % (name, t.device))
+  if t.dtype != dtype:
+    raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+  return t
+
+
+def ptr(t):
+  return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def current_stream(device):
+  return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(nbytes, device):
+  """Scratch handed to the C side; freed back to the caching allocator when
+  the returned tensor dies (stream-ordered, so safe for enqueued work)."""
+  return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def threshold_mode(nonnegative_only, hard_threshold):
+  if hard_threshold:
+    return HARD_NONNEG if nonnegative_only else HARD
+  return SOFT_NONNEG if nonnegative_only else SOFT
+
+
+def variant_code(variant):
+  assert variant in ['ista', 'fista']
+  return FISTA if variant == 'fista' else ISTA
+
+
+# ---------------------------------------------------------------------------
+# precision policy of the inference plugins (not part of the reference API:
+# the reference has one precision, float32)
+# ---------------------------------------------------------------------------
+_default_precision = os.environ.get('VTC_PRECISION', 'auto')
+
+
+def set_default_precision(name):
+  """'auto' | 'f32' | 'bf16x3' | 'bf16'.  'auto' picks bf16x3 (float32-level
+  accuracy on the bf16 matrix pipe) when the fused kernel supports the shape
+  and exact-f32 MFMA otherwise."""
+  global _default_precision
+  assert name in ('auto',) + tuple(PRECISIONS)
+  _default_precision = name
+
+
+def get_default_precision():
+  return _default_precision
+
+
+# ---------------------------------------------------------------------------
+# Lipschitz constant
+# ---------------------------------------------------------------------------
+def gram(matrix, transpose_a):
+  """A^T A (transpose_a) or A A^T of a 2-d device tensor through vtc_gram."""
+  lib = load_library()
+  rows, cols = matrix.shape
+  side = cols if transpose_a else rows
+  out = torch.empty((side, side), dtype=torch.float32, device=matrix.device)
+  check(lib.vtc_gram(ptr(matrix), rows, cols, 1 if transpose_a else 0,
+                     ptr(out), current_stream(matrix.device)), 'vtc_gram')
+  return out
+
+
+def stepsize_from_gram(gram_matrix, dictionary_for_message):
+  """eta = 1 / lambda_max.  The eigen-solve is the library call the reference
+  also delegates to (torch.symeig there, removed in torch>=2; eigvalsh is its
+  successor).  Mirrors the reference's error path: print the kernel norms and
+  raise a bare RuntimeError (ista_fista.py:75-79)."""
+  try:
+    lipschitz_constant = torch.linalg.eigvalsh(gram_matrix, UPLO='U')[-1]
+  except RuntimeError:
+    print('eigvalsh threw an exception. Likely due to one of the dictionary',
+          'elements overflowing. The norm of each dictionary element is')
+    flat = dictionary_for_message.reshape(dictionary_for_message.shape[0], -1)
+    print(torch.norm(flat, dim=1, p=2))
+    raise RuntimeError()
+  return 1. / lipschitz_constant

@@ -1,0 +1,77 @@
+"""
+Data-parallel context of the dictionary-update plugins.
+
+The reference is single-device.  Here the patch batch is sharded over the GPUs
+of a node (one process per GPU); inference needs no communication, and the
+dictionary update needs exactly one exchange: the un-normalised gradient sum
+C^T (C D - X) -- plus, for the cheap-quadratic rules, the per-atom code energy
+behind the Hessian-diagonal EMA -- is summed over ranks with one RCCL
+all-reduce per update iteration.  Every rank then divides by the GLOBAL batch
+size and applies the identical update, so dictionaries stay bit-identical.
+
+torch.distributed's "nccl" backend is RCCL on ROCm; CPU tests use "gloo".
+"""
+import torch
+import torch.distributed as dist
+
+_group = None
+_enabled = False
+_equal_shards = True
+
+
+def enable(group=None, equal_shards=True):
+  """Turn on gradient all-reduce inside dict_update_rules.*.run.
+
+  group: a torch.distributed process group (None = the default group).
+  equal_shards: every rank feeds the same local batch size, so the global
+  batch is local*world_size and no size exchange is needed.
+  """
+  global _group, _enabled, _equal_shards
+  if not dist.is_initialized():
+    raise RuntimeError('torch.distributed is not initialised')
+  _group, _enabled, _equal_shards = group, True, equal_shards
+
+
+def disable():
+  global _group, _enabled
+  _group, _enabled = None, False
+
+
+def is_enabled():
+  return _enabled and dist.is_initialized()
+
+
+def world_size():
+  return dist.get_world_size(_group) if is_enabled() else 1
+
+
+def rank():
+  return dist.get_rank(_group) if is_enabled() else 0
+
+
+def global_batch(local_batch, device):
+  """Number of samples over all ranks."""
+  if not is_enabled():
+    return int(local_batch)
+  if _equal_shards:
+    return int(local_batch) * world_size()
+  count = torch.tensor([int(local_batch)], dtype=torch.int64, device=device)
+  dist.all_reduce(count, op=dist.ReduceOp.SUM, group=_group)
+  return int(count.item())
+
+
+def all_reduce_sum_(*tensors):
+  """In-place sum over ranks.  Several small tensors are packed into one flat
+  buffer so that one collective (one launch latency) covers them: at 1 MiB the
+  exchange is latency-bound on xGMI, not bandwidth-bound."""
+  if not is_enabled() or world_size() == 1:
+    return
+  if len(tensors) == 1:
+    dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=_group)
+    return
+  flat = torch.cat([t.reshape(-1) for t in tensors])
+  dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
+  offset = 0
+  for t in tensors:
+    t.copy_(flat[offset: offset + t.numel()].view_as(t))
+    offset += t.numel()
