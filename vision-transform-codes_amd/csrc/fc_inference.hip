@@ -155,8 +155,9 @@ extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
                                  float early_stopping_epsilon, int precision,
                                  void* workspace, size_t workspace_bytes,
                                  int* iters_run, void* stream) {
-  VTC_REQUIRE(images && dictionary && codes, "vtc_fc_ista_fista: null pointer");
   VTC_REQUIRE(b >= 0 && n > 0 && s > 0, "vtc_fc_ista_fista: bad sizes");
+  VTC_REQUIRE(b == 0 || (images && dictionary && codes),
+              "vtc_fc_ista_fista: null pointer");
   VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
               "vtc_fc_ista_fista: variant must be ista or fista");
   VTC_REQUIRE(threshold >= VTC_SOFT && threshold <= VTC_HARD_NONNEG,
