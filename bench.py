@@ -47,7 +47,7 @@ def parse_args():
   ap.add_argument('--precision', default='auto',
                   choices=['auto', 'f32', 'bf16x3', 'bf16'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--cpu-sample', type=int, default=2048,
+  ap.add_argument('--cpu-sample', type=int, default=4096,
                   help='patches in the CPU-baseline sample')
   return ap.parse_args()
 
@@ -62,34 +62,61 @@ def synthetic_inputs(rank, batch, device):
   return torch.from_numpy(X).to(device), torch.from_numpy(D).to(device)
 
 
-def cpu_baseline(sample):
-  """The CPU oracle (torch CPU float32 ops in the reference's op order) timed
-  on this box's host cores on a bounded sample of the same workload."""
-  sys.path.insert(0, str(REPO / 'oracle'))
-  import sc_oracle
+def host_cores():
+  """Cores this process may really use: affinity mask, capped by the cgroup
+  CPU quota and by the 16-core share a one-GPU box grants."""
   cores = os.cpu_count() or 1
   try:
     cores = len(os.sched_getaffinity(0))
   except AttributeError:
     pass
+  try:
+    quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+    if quota != 'max':
+      cores = min(cores, max(1, int(int(quota) / int(period))))
+  except (OSError, ValueError):
+    pass
+  return max(1, min(cores, 16))
+
+
+def cpu_baseline(sample):
+  """The CPU oracle (torch CPU float32 ops in the reference's op order) timed
+  on this box's host cores on a bounded sample of the same workload: full
+  200-iteration FISTA + one update on `sample` patches, sized down if a
+  calibration run says it would take more than ~20 s."""
+  sys.path.insert(0, str(REPO / 'oracle'))
+  import sc_oracle
+  cores = host_cores()
   torch.set_num_threads(cores)
-  X = torch.from_numpy((0.1 * np.random.RandomState(0).randn(
-      sample, N_PIX)).astype(np.float32))
   D = np.random.RandomState(1).randn(N_ATOMS, N_PIX).astype(np.float32)
   D = torch.from_numpy(D / np.linalg.norm(D, axis=1, keepdims=True))
-  best = float('inf')
-  deadline = time.time() + 25.0
-  runs = 0
-  while runs < 3 and time.time() < deadline:
+  eta = sc_oracle.fc_stepsize(D)
+
+  def one_step(X):
     t0 = time.time()
-    codes = sc_oracle.fc_ista_fista(X, D, LAMBDA, FISTA_ITERS, variant='fista')
+    codes = sc_oracle.fc_ista_fista(X, D, LAMBDA, FISTA_ITERS, variant='fista',
+                                    stepsize=eta)
     sc_oracle.fc_steepest_descent(X, D.clone(), codes, stepsize=DICT_STEP)
-    best = min(best, time.time() - t0)
+    return time.time() - t0
+
+  def patches(count):
+    return torch.from_numpy((0.1 * np.random.RandomState(0).randn(
+        count, N_PIX)).astype(np.float32))
+
+  probe = one_step(patches(256))               # calibration, not reported
+  budget = 20.0
+  sample = int(max(256, min(sample, 256 * budget / max(probe, 1e-3) / 2)))
+  X = patches(sample)
+  best, runs = float('inf'), 0
+  deadline = time.time() + budget
+  while runs < 3 and (runs == 0 or time.time() < deadline):
+    best = min(best, one_step(X))
     runs += 1
   return {'value': sample / best, 'unit': 'patches/s', 'cores': cores,
           'kind': 'port',
           'sample': '%d patches x %d-iter FISTA + 1 update, best of %d, '
-                    'torch %d threads' % (sample, FISTA_ITERS, runs, cores)}
+                    'torch CPU float32, %d threads' % (
+                        sample, FISTA_ITERS, runs, cores)}
 
 
 def main():
