@@ -1,0 +1,146 @@
+"""The fused persistent FISTA kernel (bf16x3 parity mode and bf16 fast mode)
+against the golden vectors, the oracle and the exact-f32 HIP path."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import sc_oracle
+
+pytestmark = pytest.mark.gpu
+
+# bf16 fast mode: GEMM operands rounded to bf16 (8 significant bits).  SURVEY.md
+# section 7 measured 1.1e-2 relative error for that arithmetic after 200
+# iterations; the gate only says "same order of magnitude".
+REL_TOL_BF16 = 5e-2
+
+
+@pytest.fixture(scope='module')
+def ista_fista():
+  from analysis_transforms.fully_connected import ista_fista
+  if not ista_fista.fused_available():
+    pytest.fail('libvtc_hip.so was built without the fused FISTA kernel')
+  return ista_fista
+
+
+def _c2(device):
+  g = helpers.load('fc_c2_mini')
+  X = helpers.to_dev(helpers.gaussian_patches(0, 64, 256), device)
+  D = helpers.to_dev(helpers.unit_rows(1, 1024, 256), device)
+  return g, X, D, float(g['sparsity_weight']), float(g['stepsize'])
+
+
+def test_bf16x3_matches_reference_trace(device, ista_fista):
+  g, X, D, lam, eta = _c2(device)
+  for k, tol in ((1, helpers.REL_TOL_SHORT), (2, helpers.REL_TOL_SHORT),
+                 (20, 1e-5), (200, helpers.REL_TOL_F32)):
+    codes = ista_fista.run(X, D, lam, k, precision='bf16x3', stepsize=eta)
+    err, flips = helpers.assert_codes_match(
+        codes.cpu().numpy(), g['codes_fista_T%d' % k], tol,
+        'bf16x3 T=%d' % k, max_flip_mag=5e-6)
+    print('fc_c2 bf16x3 T=%d rel %.2e flips %d' % (k, err, flips))
+  truth = g['codes_fista_T200_fp64']
+  ours = ista_fista.run(X, D, lam, 200, precision='bf16x3', stepsize=eta)
+  print('vs fp64 truth: ours %.2e, reference %.2e' % (
+      helpers.rel_err(ours.cpu().numpy(), truth),
+      helpers.rel_err(g['codes_fista_T200'], truth)))
+
+
+def test_bf16_fast_mode_error_is_reported(device, ista_fista):
+  g, X, D, lam, eta = _c2(device)
+  codes = ista_fista.run(X, D, lam, 200, precision='bf16', stepsize=eta)
+  err = helpers.rel_err(codes.cpu().numpy(), g['codes_fista_T200'])
+  flips = helpers.support_mismatch(codes.cpu().numpy(), g['codes_fista_T200'])
+  print('fc_c2 bf16 T=200 rel %.2e flips %d of %d' % (
+      err, flips, g['codes_fista_T200'].size))
+  assert err < REL_TOL_BF16
+  one = ista_fista.run(X, D, lam, 1, precision='bf16', stepsize=eta)
+  assert helpers.rel_err(one.cpu().numpy(), g['codes_fista_T1']) < 2e-2
+
+
+def test_ista_warm_start_and_whitened(device, ista_fista):
+  g, X, D, lam, eta = _c2(device)
+  codes = ista_fista.run(X, D, lam, 50, variant='ista', precision='bf16x3',
+                         stepsize=eta)
+  helpers.assert_codes_match(codes.cpu().numpy(), g['codes_ista_T50'], 1e-5,
+                             'bf16x3 ista', max_flip_mag=5e-6)
+  init = helpers.to_dev(g['codes_fista_T20'], device)
+  keep = init.clone()
+  warm = ista_fista.run(X, D, lam, 20, precision='bf16x3', stepsize=eta,
+                        initial_codes=init)
+  assert torch.equal(init, keep)
+  helpers.assert_codes_match(warm.cpu().numpy(), g['codes_fista_warm20'], 1e-5,
+                             'bf16x3 warm start', max_flip_mag=5e-6)
+  w = helpers.load('whitened')
+  Xw = helpers.to_dev(w['images'], device)
+  Dw = helpers.to_dev(helpers.unit_rows(int(w['seed_dictionary']), 512, 256),
+                      device)
+  codes = ista_fista.run(Xw, Dw, float(w['sparsity_weight']), 100,
+                         precision='bf16x3', stepsize=float(w['stepsize']))
+  helpers.assert_codes_match(codes.cpu().numpy(), w['codes_fista_T100'],
+                             helpers.REL_TOL_F32, 'bf16x3 whitened (s=512)',
+                             max_flip_mag=5e-6)
+
+
+@pytest.mark.parametrize('nonneg,hard', [(True, False), (False, True),
+                                         (True, True)])
+def test_other_thresholds_against_f32_path(device, ista_fista, nonneg, hard):
+  g, X, D, lam, eta = _c2(device)
+  ref = ista_fista.run(X, D, lam, 30, precision='f32', stepsize=eta,
+                       nonnegative_only=nonneg, hard_threshold=hard)
+  out = ista_fista.run(X, D, lam, 30, precision='bf16x3', stepsize=eta,
+                       nonnegative_only=nonneg, hard_threshold=hard)
+  # a hard threshold turns a last-bit difference at the cutoff into a jump of
+  # the cutoff's size, so flips are judged by how close the pre-threshold
+  # value was: allow flips up to the cutoff itself, but bound their number
+  flips = helpers.support_mismatch(out.cpu().numpy(), ref.cpu().numpy())
+  assert flips <= 4, flips
+  same = (out != 0) == (ref != 0)
+  assert helpers.rel_err((out * same).cpu().numpy(),
+                         (ref * same).cpu().numpy()) < helpers.REL_TOL_F32
+
+
+@pytest.mark.parametrize('b', [1, 31, 33, 100])
+def test_ragged_batch_sizes(device, ista_fista, b):
+  Xn = helpers.gaussian_patches(300 + b, b, 256)
+  Dn = helpers.unit_rows(301, 256, 256)
+  eta = sc_oracle.fc_stepsize(torch.from_numpy(Dn))
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(Xn), torch.from_numpy(Dn),
+                                0.02, 30, stepsize=eta)
+  out = ista_fista.run(helpers.to_dev(Xn, device), helpers.to_dev(Dn, device),
+                       0.02, 30, precision='bf16x3', stepsize=float(eta))
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                             'ragged b=%d' % b, max_flip_mag=5e-6)
+
+
+def test_full_size_properties(device, ista_fista):
+  """BASELINE-size batch (too big for the oracle): (i) rows are independent,
+  so any slice of the batch gives bit-identical codes to the same rows of the
+  full run; (ii) the run is bitwise reproducible; (iii) bf16x3 agrees with the
+  exact-f32 HIP path on a slice."""
+  b = 131072
+  X = helpers.to_dev(helpers.gaussian_patches(11, b, 256), device)
+  D = helpers.to_dev(helpers.unit_rows(1, 1024, 256), device)
+  eta = 0.2
+  full = ista_fista.run(X, D, 0.008, 40, precision='bf16x3', stepsize=eta)
+  again = ista_fista.run(X, D, 0.008, 40, precision='bf16x3', stepsize=eta)
+  assert torch.equal(full, again)
+  part = ista_fista.run(X[4096:4096 + 320].contiguous(), D, 0.008, 40,
+                        precision='bf16x3', stepsize=eta)
+  assert torch.equal(part, full[4096:4096 + 320])
+  exact = ista_fista.run(X[:2048].contiguous(), D, 0.008, 40, precision='f32',
+                         stepsize=eta)
+  helpers.assert_codes_match(full[:2048].cpu().numpy(), exact.cpu().numpy(),
+                             5e-5, 'bf16x3 vs f32 path', max_flip_mag=5e-6)
+
+
+def test_unsupported_shapes_fall_back_or_raise(device, ista_fista):
+  X = helpers.to_dev(helpers.gaussian_patches(1, 8, 64), device)
+  D = helpers.to_dev(helpers.unit_rows(2, 64, 64), device)
+  with pytest.raises(NotImplementedError):
+    ista_fista.run(X, D, 0.05, 5, precision='bf16', stepsize=0.3)
+  # 'auto' silently picks the exact-f32 kernels for shapes the fused one
+  # does not cover (still HIP, never CPU)
+  auto = ista_fista.run(X, D, 0.05, 5, precision='auto', stepsize=0.3)
+  f32 = ista_fista.run(X, D, 0.05, 5, precision='f32', stepsize=0.3)
+  assert torch.equal(auto, f32)

@@ -1,13 +1,574 @@
-// Fused persistent FISTA kernel -- placeholder until the bf16 path lands.
+// Fused persistent FISTA kernel for 16x16 patches (n = 256) on gfx950.
+//
+// One workgroup (4 waves, one per SIMD) owns 32 patches and runs ALL the
+// iterations of analysis_transforms/fully_connected/ista_fista.py:100-146 for
+// them without touching HBM in between: the per-patch state (gradient
+// evaluation point Y, previous codes C, residual R, the patch X) lives in
+// VGPRs / LDS, only the dictionary is streamed (from L2) every iteration.
+//
+// Orientation.  Everything is computed transposed, patches on the MFMA column
+// (= lane) index:
+//     G^T[atoms x 32]  = D[atoms x 256]     . R^T[256 x 32]        ("step 1")
+//     R^T[256 x 32]   += D^T[256 x atoms]   . Ynew^T[atoms x 32]   ("step 3")
+// so that both products consume their right-hand operand with the reduction
+// index on the accumulator ROW axis: the result of one product is, after the
+// epilogue, the B operand of the next in the same lanes.
+//
+// Work split.  The atoms are walked in phases of 128 = 4 tiles of 32, one tile
+// per wave.  In phase p wave w
+//   step 1   G = D[tile 4p+w] R_k                     16 MFMA 32x32x16 (x NP)
+//   epilogue C' = shrink(Y - eta G); Y' = C' + beta (C' - C)   (f32, exact op
+//            order of the reference), Y' -> bf16 -> LDS exchange buffer
+//   barrier
+//   step 3   Racc[n-slice w] += D[phase p]^T[n-slice w] Y'[phase p]   16 MFMA
+// and after the last phase the waves exchange R_{k+1} = Racc - X through LDS.
+// The reference's two GEMMs per iteration become one sweep over D in which
+// each dictionary tile is used for the gradient (step 1) and immediately for
+// the next residual (step 3).
+//
+// Dictionary operands are pre-packed once per call into MFMA A-fragment order
+// (pack_dictionary_kernel), so every fragment load is one fully coalesced
+// 1 KiB global_load_dwordx4 per wave, straight to registers, prefetched one
+// step (16 fragments) ahead through a register ring.
+//
+// Precision (NP): 1 = single bf16 product (fast mode); 2 = bf16 hi/lo split of
+// both operands, three products hi*hi + hi*lo + lo*hi accumulated in f32
+// (bf16x3, ~2^-16 relative per product: float32-level results on the bf16
+// matrix pipe).  State, epilogue and accumulation are f32 in both.
 #include "fc_fused.h"
 
+#include <vector>
+
 namespace vtc {
-bool fused_shape_supported(int64_t, int64_t, int64_t, int) { return false; }
-size_t fused_workspace_bytes(int64_t, int64_t, int64_t, int) { return 256; }
-int run_fused(const float*, const float*, const float*, float*, int64_t,
-              int64_t, int64_t, float, float, int, int, int, int, void*,
-              size_t, int*, hipStream_t) {
-  set_error("fused FISTA kernel not built");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+
+constexpr int kFP = 32;    // patches per workgroup
+constexpr int kFN = 256;   // pixels per patch
+constexpr int kPhaseAtoms = 128;
+
+// ---------------------------------------------------------------- packing
+// packA fragment (tile t of 32 atoms, k-step ks over pixels), lane l:
+//   D[32t + (l&31)][16ks + 8(l>>5) + j],  j = 0..7
+// packT fragment (phase p, pixel block nb of 32, k-step ks over the phase's
+// atoms), lane l:
+//   D[128p + 16ks + 8(l>>5) + j][32nb + (l&31)]
+// LO = 0 stores bf16(x), LO = 1 stores bf16(x - float(bf16(x))).
+__device__ __forceinline__ __bf16 split_part(float x, int lo) {
+  const __bf16 hi = (__bf16)x;
+  if (!lo) return hi;
+  return (__bf16)(x - (float)hi);
+}
+
+__global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
+                                       __bf16* __restrict__ packA,
+                                       __bf16* __restrict__ packT, int lo) {
+  const int64_t frags = (int64_t)s * kFN / 8;  // 16-byte units per packing
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < frags;
+       u += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(u & 63);
+    const int r = l & 31, h = l >> 5;
+    {
+      const int64_t f = u >> 6;  // = t*16 + ks
+      const int t = (int)(f >> 4), ks = (int)(f & 15);
+      const float* src = D + (int64_t)(32 * t + r) * kFN + 16 * ks + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) packA[u * 8 + j] = split_part(src[j], lo);
+    }
+    {
+      const int64_t f = u >> 6;  // = (p*8 + nb)*8 + ks
+      const int ks = (int)(f & 7), nb = (int)((f >> 3) & 7), p = (int)(f >> 6);
+      const float* src =
+          D + (int64_t)(128 * p + 16 * ks + 8 * h) * kFN + 32 * nb + r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        packT[u * 8 + j] = split_part(src[(int64_t)j * kFN], lo);
+    }
+  }
+}
+
+struct FusedParams {
+  const float* images;
+  const float* init;   // may be null
+  float* codes;
+  const uint4* packA[2];  // [hi, lo]
+  const uint4* packT[2];
+  const float* betas;
+  int64_t b;
+  int s;
+  int num_iters;
+  float eta, cutoff;
+};
+
+template <int MODE>
+__device__ __forceinline__ float shrink_fast(float c, float cutoff) {
+  if (MODE == VTC_SOFT) {
+    // sign(c) * max(|c| - t, 0) == c - clamp(c, -t, t) bit for bit (up to the
+    // sign of a zero result): one v_med3 + one v_sub.
+    return sub_rn(c, __builtin_amdgcn_fmed3f(c, -cutoff, cutoff));
+  }
+  return shrink(c, cutoff, MODE);
+}
+
+__device__ __forceinline__ bf16x8 as_frag(const uint4& u) {
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+#define VTC_MFMA(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(b), c, 0, 0, 0)
+
+// LDS plan (bytes), NPH phases, NP precision parts, CREG phases of C in VGPRs:
+//   Cst : (NPH-CREG) x 16 KiB   previous codes, [phase][wave][group][lane] f32x4
+//   Yx  : 2 x NP x 8704         Y' exchange, double buffered,
+//                               [buf][part][patch][256 B + 16 B pad]
+//   Rx  : NP x 16896            R exchange, [part][patch][512 B + 16 B pad]
+// The 16-byte row pad makes the ds_read_b128 fragment reads of a 16-lane
+// group (16 different patches, same column chunk) hit 16 different 4-bank
+// slots, and keeps every address of the form lane_base + immediate.
+constexpr int kYxRow = 272;
+constexpr int kRxRow = 528;
+constexpr int kYxPart = 32 * kYxRow;   // 8704
+constexpr int kRxPart = 32 * kRxRow;   // 16896
+
+template <int NPH, int NP>
+struct FusedLds {
+  static constexpr int CREG_WANT = (NP == 1) ? 1 : 3;
+  static constexpr int CREG = CREG_WANT < NPH ? CREG_WANT : NPH;
+  static constexpr int CL = NPH - CREG;
+  static constexpr int cst_bytes = CL * 16384;
+  static constexpr int yx_bytes = 2 * NP * kYxPart;
+  static constexpr int rx_bytes = NP * kRxPart;
+  static constexpr int total = cst_bytes + yx_bytes + rx_bytes;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc,
+                                               unsigned voff, unsigned soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <int NPH, int NP, int MODE>
+__global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
+  using L = FusedLds<NPH, NP>;
+  constexpr int CREG = L::CREG;
+  constexpr int CR = CREG > 0 ? CREG : 1;
+  constexpr int RING = (NP == 1) ? 16 : 8;  // fragments (k-steps) in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Cst = smem;
+  char* Yx = smem + L::cst_bytes;
+  char* Rx = Yx + L::yx_bytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t patch = (int64_t)blockIdx.x * kFP + r;
+  const bool live = patch < P.b;
+  const int s = P.s;
+
+  // Dictionary fragments through buffer loads: wave-uniform descriptor (base
+  // already offset to this wave's share), one VGPR byte offset (lane * 16),
+  // the fragment index as a scalar offset.
+  const unsigned pack_bytes_total = (unsigned)s * kFN * 2u;
+  const unsigned a_wave_off = (unsigned)w * (16u * 64u * 16u);
+  const unsigned t_wave_off = (unsigned)(2 * w) * (8u * 64u * 16u);
+  __amdgpu_buffer_rsrc_t rsA[NP], rsT[NP];
+#pragma unroll
+  for (int part = 0; part < NP; ++part) {
+    rsA[part] = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)P.packA[part] + a_wave_off), 0,
+        (int)(pack_bytes_total - a_wave_off), 0x00020000);
+    rsT[part] = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)P.packT[part] + t_wave_off), 0,
+        (int)(pack_bytes_total - t_wave_off), 0x00020000);
+  }
+  const unsigned frag_voff = (unsigned)lane * 16u;
+  //   packA fragment (phase p, k-step i):      ((4p) * 16 + i) * 1024 bytes
+  //   packT fragment (phase p, block nb, ks):  ((p * 8 + nb) * 8 + ks) * 1024
+#define VTC_LOAD_A(part, p, i) \
+  buffer_load16(rsA[part], frag_voff, (unsigned)(((4 * (p)) * 16 + (i)) * 1024))
+#define VTC_LOAD_T(part, p, nb, ks) \
+  buffer_load16(rsT[part], frag_voff,  \
+                (unsigned)((((p) * 8 + (nb)) * 8 + (ks)) * 1024))
+
+  // LDS lane bases
+  const int yx_rd = r * kYxRow + 16 * h;            // + 32 ks
+  const int yx_wr = r * kYxRow + 64 * w + 8 * h;    // + 16 g
+  const int rx_rd = r * kRxRow + 16 * h;            // + 32 ks
+  const int rx_wr = r * kRxRow + 128 * w + 8 * h;   // + 64 nb + 16 g
+  const int cst_ln = w * 4096 + lane * 16;          // + pl*16384 + g*1024
+
+  // ---- per-wave state --------------------------------------------------
+  f32x16v Y[NPH];    // gradient evaluation point, this wave's tile per phase
+  f32x16v Cr[CR];    // previous codes of the first CREG phases
+  f32x16v Xr[2];     // the patches, this wave's two 32-pixel blocks
+  f32x16v Racc[2];
+  uint4 ring[NP][RING];
+
+  // element e of a 32x32 accumulator: row (e&3) + 8(e>>2) + 4h, column r
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live)
+        v = *reinterpret_cast<const float4*>(
+            P.images + patch * kFN + 64 * w + 32 * nb + 8 * g + 4 * h);
+      Xr[nb][4 * g + 0] = v.x;
+      Xr[nb][4 * g + 1] = v.y;
+      Xr[nb][4 * g + 2] = v.z;
+      Xr[nb][4 * g + 3] = v.w;
+    }
+  }
+  const bool warm = (P.init != nullptr);
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (warm && live)
+        v = *reinterpret_cast<const float4*>(
+            P.init + patch * s + kPhaseAtoms * p + 32 * w + 8 * g + 4 * h);
+      Y[p][4 * g + 0] = v.x;
+      Y[p][4 * g + 1] = v.y;
+      Y[p][4 * g + 2] = v.z;
+      Y[p][4 * g + 3] = v.w;
+      if (p < CREG) {
+        Cr[p < CREG ? p : 0][4 * g + 0] = v.x;
+        Cr[p < CREG ? p : 0][4 * g + 1] = v.y;
+        Cr[p < CREG ? p : 0][4 * g + 2] = v.z;
+        Cr[p < CREG ? p : 0][4 * g + 3] = v.w;
+      } else {
+        *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
+                                   g * 1024) = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
+
+  // write the wave's tile of Y (as bf16 parts) into exchange buffer `buf`
+  auto publish_y = [&](const f32x16v& y, int buf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = y[4 * g + k];
+        hi[k] = (__bf16)v;
+        if (NP == 2) lo[k] = (__bf16)(v - (float)hi[k]);
+      }
+      char* dst = Yx + buf * NP * kYxPart + yx_wr + 16 * g;
+      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
+      if (NP == 2)
+        *reinterpret_cast<uint2*>(dst + kYxPart) =
+            __builtin_bit_cast(uint2, lo);
+    }
+  };
+
+  // step 3 of one phase: Racc[nb] += D^T fragments x Y' fragments.
+  // pipe: fragments come from the ring, whose slots are refilled with the
+  // step-1 fragments of phase next_p; otherwise they are loaded on the spot.
+  auto step3 = [&](int p, int buf, bool pipe, int next_p) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      uint4 yb[NP];
+#pragma unroll
+      for (int part = 0; part < NP; ++part)
+        yb[part] = *reinterpret_cast<const uint4*>(
+            Yx + (buf * NP + part) * kYxPart + yx_rd + 32 * ks);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int i = 2 * ks + nb;          // position in the step-3 stream
+        const int slot = i % RING;
+        uint4 a[NP];
+#pragma unroll
+        for (int part = 0; part < NP; ++part)
+          a[part] = pipe ? ring[part][slot] : VTC_LOAD_T(part, p, nb, ks);
+        Racc[nb] = VTC_MFMA(a[0], yb[0], Racc[nb]);
+        if (NP == 2) {
+          Racc[nb] = VTC_MFMA(a[0], yb[1], Racc[nb]);
+          Racc[nb] = VTC_MFMA(a[1], yb[0], Racc[nb]);
+        }
+        if (pipe) {
+          // stream position i + RING: still step 3 of this phase, or step 1
+          // of the next one
+          const int j = i + RING;
+#pragma unroll
+          for (int part = 0; part < NP; ++part)
+            ring[part][slot] = (j < 16)
+                ? VTC_LOAD_T(part, p, j & 1, j >> 1)
+                : VTC_LOAD_A(part, next_p, j - 16);
+        }
+      }
+    }
+  };
+
+  // R_{k+1} = Racc - X  ->  bf16 parts -> LDS (read back as B fragments by
+  // every wave during step 1 of the next iteration)
+  auto exchange_r = [&]() {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = sub_rn(Racc[nb][4 * g + k], Xr[nb][4 * g + k]);
+          hi[k] = (__bf16)v;
+          if (NP == 2) lo[k] = (__bf16)(v - (float)hi[k]);
+        }
+        char* dst = Rx + rx_wr + 64 * nb + 16 * g;
+        *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
+        if (NP == 2)
+          *reinterpret_cast<uint2*>(dst + kRxPart) =
+              __builtin_bit_cast(uint2, lo);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
+    __syncthreads();
+  };
+
+  // ---- R_0 = Y_0 D - X ---------------------------------------------------
+  if (warm) {
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      publish_y(Y[p], p & 1);
+      __syncthreads();
+      step3(p, p & 1, false, 0);
+    }
+  }
+  exchange_r();
+
+  // prime the ring with the first RING step-1 fragments of phase 0
+#pragma unroll
+  for (int i = 0; i < RING; ++i)
+#pragma unroll
+    for (int part = 0; part < NP; ++part)
+      ring[part][i] = VTC_LOAD_A(part, 0, i);
+
+  const float eta = P.eta, cutoff = P.cutoff;
+  for (int it = 0; it < P.num_iters; ++it) {
+    const float beta = P.betas[it];
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      // ---- step 1: G = D[tile] R_k   (stream positions 0..15 of the phase)
+      f32x16v G;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) G[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int slot = i % RING;
+        uint4 rb[NP];
+#pragma unroll
+        for (int part = 0; part < NP; ++part)
+          rb[part] = *reinterpret_cast<const uint4*>(Rx + part * kRxPart +
+                                                     rx_rd + 32 * i);
+        G = VTC_MFMA(ring[0][slot], rb[0], G);
+        if (NP == 2) {
+          G = VTC_MFMA(ring[0][slot], rb[1], G);
+          G = VTC_MFMA(ring[1][slot], rb[0], G);
+        }
+        const int j = i + RING;  // refill with stream position j
+#pragma unroll
+        for (int part = 0; part < NP; ++part)
+          ring[part][slot] = (j < 16)
+              ? VTC_LOAD_A(part, p, j)
+              : VTC_LOAD_T(part, p, (j - 16) & 1, (j - 16) >> 1);
+      }
+      // ---- proximal step + extrapolation (ista_fista.py:105-131)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 cold;
+        if (p < CREG) {
+          cold = make_float4(Cr[p < CREG ? p : 0][4 * g + 0],
+                             Cr[p < CREG ? p : 0][4 * g + 1],
+                             Cr[p < CREG ? p : 0][4 * g + 2],
+                             Cr[p < CREG ? p : 0][4 * g + 3]);
+        } else {
+          cold = *reinterpret_cast<const float4*>(
+              Cst + cst_ln + (p - CREG) * 16384 + g * 1024);
+        }
+        const float co[4] = {cold.x, cold.y, cold.z, cold.w};
+        float cn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * g + k;
+          const float c = sub_rn(Y[p][e], mul_rn(eta, G[e]));
+          cn[k] = shrink_fast<MODE>(c, cutoff);
+          const float d = sub_rn(cn[k], co[k]);
+          Y[p][e] = add_rn(cn[k], mul_rn(beta, d));
+        }
+        if (p < CREG) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) Cr[p < CREG ? p : 0][4 * g + k] = cn[k];
+        } else {
+          *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
+                                     g * 1024) =
+              make_float4(cn[0], cn[1], cn[2], cn[3]);
+        }
+      }
+      publish_y(Y[p], p & 1);
+      __syncthreads();
+      // ---- step 3: next residual, this wave's 64 pixels
+      step3(p, p & 1, true, (p + 1) % NPH);
+    }
+    exchange_r();
+  }
+
+  // ---- codes out: the last C -----------------------------------------
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v;
+      if (p < CREG) {
+        v = make_float4(Cr[p < CREG ? p : 0][4 * g + 0],
+                        Cr[p < CREG ? p : 0][4 * g + 1],
+                        Cr[p < CREG ? p : 0][4 * g + 2],
+                        Cr[p < CREG ? p : 0][4 * g + 3]);
+      } else {
+        v = *reinterpret_cast<const float4*>(Cst + cst_ln +
+                                             (p - CREG) * 16384 + g * 1024);
+      }
+      if (live)
+        *reinterpret_cast<float4*>(P.codes + patch * s + kPhaseAtoms * p +
+                                   32 * w + 8 * g + 4 * h) = v;
+    }
+  }
+#undef VTC_LOAD_A
+#undef VTC_LOAD_T
+}
+
+// -------------------------------------------------------------------- host
+static int phases_for(int64_t s) { return (int)(s / kPhaseAtoms); }
+
+bool fused_shape_supported(int64_t b, int64_t n, int64_t s, int precision) {
+  if (n != kFN || b <= 0) return false;
+  if (s % kPhaseAtoms != 0) return false;
+  const int nph = phases_for(s);
+  if (!(nph == 2 || nph == 4 || nph == 8)) return false;
+  return precision == VTC_BF16 || precision == VTC_BF16X3;
+}
+
+static size_t pack_bytes(int64_t s) { return (size_t)s * kFN * sizeof(__bf16); }
+
+size_t fused_workspace_bytes(int64_t b, int64_t n, int64_t s, int precision) {
+  if (!fused_shape_supported(b, n, s, precision)) return 256;
+  const int parts = (precision == VTC_BF16X3) ? 2 : 1;
+  return (size_t)parts * 2 * align_up(pack_bytes(s), 256) + 4096 * sizeof(float);
+}
+
+template <int NPH, int NP, int MODE>
+static int launch_fused(const FusedParams& P, hipStream_t st) {
+  using L = FusedLds<NPH, NP>;
+  auto kernel = fused_fista_kernel<NPH, NP, MODE>;
+  static bool configured = false;
+  if (!configured) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+    configured = true;
+  }
+  const unsigned grid = (unsigned)ceil_div(P.b, kFP);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+template <int NPH, int NP>
+static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
+  switch (threshold) {
+    case VTC_SOFT: return launch_fused<NPH, NP, VTC_SOFT>(P, st);
+    case VTC_SOFT_NONNEG: return launch_fused<NPH, NP, VTC_SOFT_NONNEG>(P, st);
+    case VTC_HARD: return launch_fused<NPH, NP, VTC_HARD>(P, st);
+    default: return launch_fused<NPH, NP, VTC_HARD_NONNEG>(P, st);
+  }
+}
+
+template <int NP>
+static int dispatch_phases(const FusedParams& P, int threshold,
+                           hipStream_t st) {
+  switch (phases_for(P.s)) {
+    case 2: return dispatch_mode<2, NP>(P, threshold, st);
+    case 4: return dispatch_mode<4, NP>(P, threshold, st);
+    case 8: return dispatch_mode<8, NP>(P, threshold, st);
+  }
+  set_error("fused FISTA: unsupported atom count %d", P.s);
   return VTC_ERR_UNSUPPORTED;
 }
+
+int run_fused(const float* images, const float* dictionary,
+              const float* initial_codes, float* codes, int64_t b, int64_t n,
+              int64_t s, float eta, float cutoff, int num_iters, int variant,
+              int threshold, int precision, void* workspace,
+              size_t workspace_bytes, int* iters_run, hipStream_t st) {
+  if (!fused_shape_supported(b, n, s, precision)) {
+    set_error("fused FISTA: unsupported shape");
+    return VTC_ERR_UNSUPPORTED;
+  }
+  if (num_iters > 4096) {
+    set_error("fused FISTA: at most 4096 iterations per call");
+    return VTC_ERR_UNSUPPORTED;
+  }
+  if (!workspace ||
+      workspace_bytes < fused_workspace_bytes(b, n, s, precision)) {
+    set_error("fused FISTA: workspace too small");
+    return VTC_ERR_WORKSPACE;
+  }
+  const int parts = (precision == VTC_BF16X3) ? 2 : 1;
+  Carver ws(workspace);
+  FusedParams P;
+  __bf16* packs[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int part = 0; part < parts; ++part) {
+    packs[2 * part] = ws.take<__bf16>((size_t)s * kFN);
+    packs[2 * part + 1] = ws.take<__bf16>((size_t)s * kFN);
+  }
+  float* betas_dev = ws.take<float>(4096);
+  for (int part = 0; part < parts; ++part) {
+    hipLaunchKernelGGL(pack_dictionary_kernel, dim3(256), dim3(256), 0, st,
+                       dictionary, (int)s, packs[2 * part],
+                       packs[2 * part + 1], part);
+    VTC_LAUNCH_CHECK();
+  }
+  // ISTA is FISTA with beta = 0: y = c + 0 * (c - c_prev) = c exactly
+  std::vector<float> betas;
+  fista_betas(num_iters, &betas);
+  if (variant == VTC_ISTA)
+    for (auto& v : betas) v = 0.f;
+  // the staging buffer must outlive the async copy: keep it per thread
+  static thread_local std::vector<float> staged;
+  staged = betas;
+  VTC_HIP_CHECK(hipMemcpyAsync(betas_dev, staged.data(),
+                               sizeof(float) * num_iters,
+                               hipMemcpyHostToDevice, st));
+  P.images = images;
+  P.init = initial_codes;
+  P.codes = codes;
+  for (int part = 0; part < 2; ++part) {
+    P.packA[part] = reinterpret_cast<const uint4*>(packs[2 * (part % parts)]);
+    P.packT[part] =
+        reinterpret_cast<const uint4*>(packs[2 * (part % parts) + 1]);
+  }
+  P.betas = betas_dev;
+  P.b = b;
+  P.s = (int)s;
+  P.num_iters = num_iters;
+  P.eta = eta;
+  P.cutoff = cutoff;
+  int rc = (parts == 2) ? dispatch_phases<2>(P, threshold, st)
+                        : dispatch_phases<1>(P, threshold, st);
+  if (rc == VTC_OK && iters_run) *iters_run = num_iters;
+  return rc;
+}
+
 }  // namespace vtc
