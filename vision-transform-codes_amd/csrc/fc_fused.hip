@@ -276,13 +276,26 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   // pipe: fragments come from the ring, whose slots are refilled with the
   // step-1 fragments of phase next_p; otherwise they are loaded on the spot.
   auto step3 = [&](int p, int buf, bool pipe, int next_p) {
+    // Y' fragments are read one k-step ahead of their use.  hipcc would
+    // otherwise sink every dictionary load down to its consumer (to shorten
+    // live ranges), which serialises load -> wait -> MFMA; the sched_barrier
+    // after each k-step pins the issue order written here: MFMA, then the
+    // refill of the ring slot it just consumed.
+    uint4 yb_next[NP];
+#pragma unroll
+    for (int part = 0; part < NP; ++part)
+      yb_next[part] = *reinterpret_cast<const uint4*>(
+          Yx + (buf * NP + part) * kYxPart + yx_rd);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       uint4 yb[NP];
 #pragma unroll
-      for (int part = 0; part < NP; ++part)
-        yb[part] = *reinterpret_cast<const uint4*>(
-            Yx + (buf * NP + part) * kYxPart + yx_rd + 32 * ks);
+      for (int part = 0; part < NP; ++part) {
+        yb[part] = yb_next[part];
+        if (ks + 1 < 8)
+          yb_next[part] = *reinterpret_cast<const uint4*>(
+              Yx + (buf * NP + part) * kYxPart + yx_rd + 32 * (ks + 1));
+      }
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         const int i = 2 * ks + nb;          // position in the step-3 stream
@@ -306,6 +319,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
                 ? VTC_LOAD_T(part, p, j & 1, j >> 1)
                 : VTC_LOAD_A(part, next_p, j - 16);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -365,14 +379,22 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
       f32x16v G;
 #pragma unroll
       for (int e = 0; e < 16; ++e) G[e] = 0.f;
+      uint4 rb_next[NP];
+#pragma unroll
+      for (int part = 0; part < NP; ++part)
+        rb_next[part] =
+            *reinterpret_cast<const uint4*>(Rx + part * kRxPart + rx_rd);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int slot = i % RING;
         uint4 rb[NP];
 #pragma unroll
-        for (int part = 0; part < NP; ++part)
-          rb[part] = *reinterpret_cast<const uint4*>(Rx + part * kRxPart +
-                                                     rx_rd + 32 * i);
+        for (int part = 0; part < NP; ++part) {
+          rb[part] = rb_next[part];
+          if (i + 1 < 16)
+            rb_next[part] = *reinterpret_cast<const uint4*>(
+                Rx + part * kRxPart + rx_rd + 32 * (i + 1));
+        }
         G = VTC_MFMA(ring[0][slot], rb[0], G);
         if (NP == 2) {
           G = VTC_MFMA(ring[0][slot], rb[1], G);
@@ -384,6 +406,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
           ring[part][slot] = (j < 16)
               ? VTC_LOAD_A(part, p, j)
               : VTC_LOAD_T(part, p, (j - 16) & 1, (j - 16) >> 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // ---- proximal step + extrapolation (ista_fista.py:105-131)
 #pragma unroll
