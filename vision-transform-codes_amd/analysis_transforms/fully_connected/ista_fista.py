@@ -77,12 +77,14 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
   iters_run = ctypes.c_int(0)
   eps = -1.0 if early_stopping_epsilon is None else float(
       early_stopping_epsilon)
-  vtc_hip.check(lib.vtc_fc_ista_fista(
-      vtc_hip.ptr(images), vtc_hip.ptr(dictionary), vtc_hip.ptr(initial_codes),
-      vtc_hip.ptr(codes), b, n, s, eta, lam, int(num_iters),
-      vtc_hip.variant_code(variant), mode, eps, prec, vtc_hip.ptr(ws),
-      ws.numel(), ctypes.byref(iters_run),
-      vtc_hip.current_stream(images.device)), 'vtc_fc_ista_fista')
+  with vtc_hip.timed_call(images.device):
+    status = lib.vtc_fc_ista_fista(
+        vtc_hip.ptr(images), vtc_hip.ptr(dictionary),
+        vtc_hip.ptr(initial_codes), vtc_hip.ptr(codes), b, n, s, eta, lam,
+        int(num_iters), vtc_hip.variant_code(variant), mode, eps, prec,
+        vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run),
+        vtc_hip.current_stream(images.device))
+  vtc_hip.check(status, 'vtc_fc_ista_fista')
   run.last_iters = iters_run.value
   return codes
 

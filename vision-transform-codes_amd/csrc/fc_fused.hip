@@ -37,6 +37,7 @@
 // matrix pipe).  State, epilogue and accumulation are f32 in both.
 #include "fc_fused.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace vtc {
@@ -100,6 +101,7 @@ struct FusedParams {
   int s;
   int num_iters;
   float eta, cutoff;
+  unsigned long long* stamps;  // diagnostic build only: 8 cycle sums
 };
 
 template <int MODE>
@@ -151,7 +153,17 @@ __device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t rsrc,
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-template <int NPH, int NP, int MODE>
+// In-kernel stamps (diagnostic instantiation only, STAMP = true): where a
+// phase spends its cycles.  s_memtime + its wait in one statement, fenced.
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+template <int NPH, int NP, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   using L = FusedLds<NPH, NP>;
   constexpr int CREG = L::CREG;
@@ -371,6 +383,15 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
       ring[part][i] = VTC_LOAD_A(part, 0, i);
 
   const float eta = P.eta, cutoff = P.cutoff;
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+  unsigned long long t0 = 0, t1 = 0;
+#define VTC_STAMP(slot)                    \
+  if (STAMP) {                             \
+    t1 = stamp_now();                      \
+    acc_t[slot] += t1 - t0;                \
+    t0 = t1;                               \
+  }
+  if (STAMP) t0 = stamp_now();
   for (int it = 0; it < P.num_iters; ++it) {
     const float beta = P.betas[it];
 #pragma unroll
@@ -408,6 +429,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
               : VTC_LOAD_T(part, p, (j - 16) & 1, (j - 16) >> 1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      VTC_STAMP(0)
       // ---- proximal step + extrapolation (ista_fista.py:105-131)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -441,12 +463,22 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
         }
       }
       publish_y(Y[p], p & 1);
+      VTC_STAMP(1)
       __syncthreads();
+      VTC_STAMP(2)
       // ---- step 3: next residual, this wave's 64 pixels
       step3(p, p & 1, true, (p + 1) % NPH);
+      VTC_STAMP(3)
     }
     exchange_r();
+    VTC_STAMP(4)
   }
+  if (STAMP && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) atomicAdd(P.stamps + k, acc_t[k]);
+    atomicAdd(P.stamps + 7, 1ull);
+  }
+#undef VTC_STAMP
 
   // ---- codes out: the last C -----------------------------------------
 #pragma unroll
@@ -508,8 +540,42 @@ static int launch_fused(const FusedParams& P, hipStream_t st) {
   return VTC_OK;
 }
 
+// Diagnostic: VTC_FUSED_STAMPS=1 runs the stamped instantiation (soft
+// threshold only) and prints per-segment cycle shares.  Its run time is not
+// representative (the stamps fence the schedule); read the shares only.
+template <int NPH, int NP>
+static int launch_stamped(FusedParams P, hipStream_t st) {
+  using L = FusedLds<NPH, NP>;
+  auto kernel = fused_fista_kernel<NPH, NP, VTC_SOFT, true>;
+  unsigned long long* dev = nullptr;
+  VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
+  VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
+  VTC_HIP_CHECK(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+  P.stamps = dev;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
+                     L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  unsigned long long host[8];
+  VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost,
+                               st));
+  VTC_HIP_CHECK(hipStreamSynchronize(st));
+  VTC_HIP_CHECK(hipFree(dev));
+  const char* names[5] = {"step1", "epilogue", "barrier", "step3", "exchange"};
+  double total = 0;
+  for (int k = 0; k < 5; ++k) total += (double)host[k];
+  const double per = (double)host[7] * P.num_iters * NPH;
+  for (int k = 0; k < 5; ++k)
+    fprintf(stderr, "[vtc stamps] %-9s %5.1f%%  %8.0f cycles/phase/wave\n",
+            names[k], 100.0 * host[k] / total, host[k] / per);
+  return VTC_OK;
+}
+
 template <int NPH, int NP>
 static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
+  if (threshold == VTC_SOFT && NPH == 8 && getenv("VTC_FUSED_STAMPS"))
+    return launch_stamped<NPH, NP>(P, st);
   switch (threshold) {
     case VTC_SOFT: return launch_fused<NPH, NP, VTC_SOFT>(P, st);
     case VTC_SOFT_NONNEG: return launch_fused<NPH, NP, VTC_SOFT_NONNEG>(P, st);
@@ -588,6 +654,7 @@ int run_fused(const float* images, const float* dictionary,
   P.num_iters = num_iters;
   P.eta = eta;
   P.cutoff = cutoff;
+  P.stamps = nullptr;
   int rc = (parts == 2) ? dispatch_phases<2>(P, threshold, st)
                         : dispatch_phases<1>(P, threshold, st);
   if (rc == VTC_OK && iters_run) *iters_run = num_iters;

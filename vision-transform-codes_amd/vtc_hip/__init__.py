@@ -189,6 +189,34 @@ def get_default_precision():
 
 
 # ---------------------------------------------------------------------------
+# optional device-side timing of the inference entry point (bench.py uses it to
+# time the FISTA kernel itself, without the Lipschitz eigen-solve around it)
+# ---------------------------------------------------------------------------
+kernel_timing = None   # None, or a list that receives (start, stop) events
+
+
+class timed_call(object):
+  """with timed_call(device): lib.vtc_...()  -- records a pair of events on
+  the current stream when kernel_timing is a list."""
+
+  def __init__(self, device):
+    self.device = device
+
+  def __enter__(self):
+    if kernel_timing is not None:
+      self.start = torch.cuda.Event(enable_timing=True)
+      self.stop = torch.cuda.Event(enable_timing=True)
+      self.start.record(torch.cuda.current_stream(self.device))
+    return self
+
+  def __exit__(self, *exc):
+    if kernel_timing is not None:
+      self.stop.record(torch.cuda.current_stream(self.device))
+      kernel_timing.append((self.start, self.stop))
+    return False
+
+
+# ---------------------------------------------------------------------------
 # Lipschitz constant
 # ---------------------------------------------------------------------------
 def gram(matrix, transpose_a):
