@@ -139,8 +139,10 @@ def main():
   from analysis_transforms.fully_connected import ista_fista
   from dict_update_rules.fully_connected import sc_steepest_descent
 
-  if world > 1:
-    import torch.distributed as dist
+  import torch.distributed as dist
+  launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+  if world > 1 or launched:
+    # one process per GPU; "nccl" is RCCL on ROCm (xGMI between the GPUs)
     dist.init_process_group('nccl', rank=rank, world_size=world,
                             device_id=device)
     parallel.enable()
@@ -158,7 +160,7 @@ def main():
     return codes
 
   def fence():
-    if world > 1:
+    if dist.is_initialized():
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -174,7 +176,7 @@ def main():
   fence()
   elapsed = time.perf_counter() - t0
   vtc_hip.kernel_timing = None
-  if world > 1:
+  if dist.is_initialized():
     worst = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
     elapsed = float(worst.item())
@@ -235,7 +237,7 @@ def main():
     else:
       result['cpu_baseline'] = None
     print(json.dumps(result))
-  if world > 1:
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
 

@@ -284,15 +284,39 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
     }
   };
 
-  // step 3 of one phase: Racc[nb] += D^T fragments x Y' fragments.
-  // pipe: fragments come from the ring, whose slots are refilled with the
-  // step-1 fragments of phase next_p; otherwise they are loaded on the spot.
-  auto step3 = [&](int p, int buf, bool pipe, int next_p) {
-    // Y' fragments are read one k-step ahead of their use.  hipcc would
-    // otherwise sink every dictionary load down to its consumer (to shorten
-    // live ranges), which serialises load -> wait -> MFMA; the sched_barrier
-    // after each k-step pins the issue order written here: MFMA, then the
-    // refill of the ring slot it just consumed.
+  // Per iteration the dictionary is consumed as a stream of 2*NPH segments of
+  // 16 fragments; the epilogue of phase p is software-pipelined under step 1
+  // of phase p+1, so the order is
+  //   A(0) | A(1) T(0) | A(2) T(1) | ... | A(NPH-1) T(NPH-2) | T(NPH-1)
+  // (A(p) = step-1 fragments of phase p, T(p) = its step-3 fragments).
+  // Segment sigma: is it a T segment, and of which phase?
+#define VTC_SEG_IS_T(sg) (((sg) >= 2 && ((sg) % 2) == 0) || (sg) == 2 * NPH - 1)
+#define VTC_SEG_PHASE(sg)                                        \
+  ((sg) == 0 ? 0                                                 \
+             : (sg) == 2 * NPH - 1 ? NPH - 1                     \
+                                   : ((sg) % 2 ? ((sg) + 1) / 2 : (sg) / 2 - 1))
+#define VTC_LOAD_SEG(part, sg, i)                                          \
+  (VTC_SEG_IS_T(sg) ? VTC_LOAD_T(part, VTC_SEG_PHASE(sg), (i) & 1, (i) >> 1) \
+                    : VTC_LOAD_A(part, VTC_SEG_PHASE(sg), (i)))
+  // refill of the ring slot consumed at (segment sg, position i): the
+  // fragment RING positions further down the stream (wrapping to the next
+  // iteration's first segment)
+#define VTC_REFILL(sg, i)                                                   \
+  {                                                                         \
+    const int j_ = (i) + RING;                                              \
+    const int sg_ = (j_ < 16) ? (sg) : (((sg) + 1) % (2 * NPH));            \
+    const int i_ = (j_ < 16) ? j_ : j_ - 16;                                \
+    _Pragma("unroll") for (int part = 0; part < NP; ++part)                 \
+        ring[part][(i) % RING] = VTC_LOAD_SEG(part, sg_, i_);               \
+  }
+
+  // step 3 of phase p: Racc[nb] += D^T fragments x Y' fragments.
+  // pipe: fragments come from the ring (stream segment sg); otherwise they
+  // are loaded on the spot (warm-start prologue).
+  // hipcc would sink every dictionary load down to its consumer (to shorten
+  // live ranges), which serialises load -> wait -> MFMA; the sched_barrier
+  // after each k-step pins the issue order written here.
+  auto step3 = [&](int p, int buf, bool pipe, int sg) {
     uint4 yb_next[NP];
 #pragma unroll
     for (int part = 0; part < NP; ++part)
@@ -310,27 +334,17 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
       }
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const int i = 2 * ks + nb;          // position in the step-3 stream
-        const int slot = i % RING;
+        const int i = 2 * ks + nb;          // position in the segment
         uint4 a[NP];
 #pragma unroll
         for (int part = 0; part < NP; ++part)
-          a[part] = pipe ? ring[part][slot] : VTC_LOAD_T(part, p, nb, ks);
+          a[part] = pipe ? ring[part][i % RING] : VTC_LOAD_T(part, p, nb, ks);
         Racc[nb] = VTC_MFMA(a[0], yb[0], Racc[nb]);
         if (NP == 2) {
           Racc[nb] = VTC_MFMA(a[0], yb[1], Racc[nb]);
           Racc[nb] = VTC_MFMA(a[1], yb[0], Racc[nb]);
         }
-        if (pipe) {
-          // stream position i + RING: still step 3 of this phase, or step 1
-          // of the next one
-          const int j = i + RING;
-#pragma unroll
-          for (int part = 0; part < NP; ++part)
-            ring[part][slot] = (j < 16)
-                ? VTC_LOAD_T(part, p, j & 1, j >> 1)
-                : VTC_LOAD_A(part, next_p, j - 16);
-        }
+        if (pipe) VTC_REFILL(sg, i)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -375,12 +389,12 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   }
   exchange_r();
 
-  // prime the ring with the first RING step-1 fragments of phase 0
+  // prime the ring with the first RING fragments of segment 0
 #pragma unroll
   for (int i = 0; i < RING; ++i)
 #pragma unroll
     for (int part = 0; part < NP; ++part)
-      ring[part][i] = VTC_LOAD_A(part, 0, i);
+      ring[part][i] = VTC_LOAD_SEG(part, 0, i);
 
   const float eta = P.eta, cutoff = P.cutoff;
   unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
@@ -392,82 +406,108 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
     t0 = t1;                               \
   }
   if (STAMP) t0 = stamp_now();
+
+  f32x16v Gb[2];     // gradient tiles of two consecutive phases
+  float4 cold4;      // previous codes of the 4 elements being processed
+  float cn4[4];
+
+  // Proximal step + extrapolation for element e of phase p
+  // (ista_fista.py:105-131); elements are visited in order 0..15, group
+  // loads/stores of C and the bf16 publication of Y' happen at group edges.
+  auto epilogue_elem = [&](int p, int e, const f32x16v& Gp, float beta) {
+    const int g = e >> 2, k = e & 3;
+    if (k == 0) {
+      if (p < CREG) {
+        cold4 = make_float4(Cr[p < CREG ? p : 0][4 * g + 0],
+                            Cr[p < CREG ? p : 0][4 * g + 1],
+                            Cr[p < CREG ? p : 0][4 * g + 2],
+                            Cr[p < CREG ? p : 0][4 * g + 3]);
+      } else {
+        cold4 = *reinterpret_cast<const float4*>(
+            Cst + cst_ln + (p - CREG) * 16384 + g * 1024);
+      }
+    }
+    const float co = (k == 0) ? cold4.x : (k == 1) ? cold4.y
+                   : (k == 2) ? cold4.z : cold4.w;
+    const float c = sub_rn(Y[p][e], mul_rn(eta, Gp[e]));
+    const float cn = shrink_fast<MODE>(c, cutoff);
+    const float d = sub_rn(cn, co);
+    Y[p][e] = add_rn(cn, mul_rn(beta, d));
+    cn4[k] = cn;
+    if (k == 3) {
+      if (p < CREG) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Cr[p < CREG ? p : 0][4 * g + q] = cn4[q];
+      } else {
+        *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
+                                   g * 1024) =
+            make_float4(cn4[0], cn4[1], cn4[2], cn4[3]);
+      }
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = Y[p][4 * g + q];
+        hi[q] = (__bf16)v;
+        if (NP == 2) lo[q] = (__bf16)(v - (float)hi[q]);
+      }
+      char* dst = Yx + (p & 1) * NP * kYxPart + yx_wr + 16 * g;
+      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
+      if (NP == 2)
+        *reinterpret_cast<uint2*>(dst + kYxPart) =
+            __builtin_bit_cast(uint2, lo);
+    }
+  };
+
+  // step 1 of phase p (stream segment sg): Gb[p&1] = D[tile] R_k, with the
+  // epilogue of phase p-1 interleaved element by element when `overlap`
+  auto step1 = [&](int p, int sg, bool overlap, float beta) {
+    f32x16v& G = Gb[p & 1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) G[e] = 0.f;
+    uint4 rb_next[NP];
+#pragma unroll
+    for (int part = 0; part < NP; ++part)
+      rb_next[part] =
+          *reinterpret_cast<const uint4*>(Rx + part * kRxPart + rx_rd);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      uint4 rb[NP];
+#pragma unroll
+      for (int part = 0; part < NP; ++part) {
+        rb[part] = rb_next[part];
+        if (i + 1 < 16)
+          rb_next[part] = *reinterpret_cast<const uint4*>(
+              Rx + part * kRxPart + rx_rd + 32 * (i + 1));
+      }
+      G = VTC_MFMA(ring[0][i % RING], rb[0], G);
+      if (NP == 2) {
+        G = VTC_MFMA(ring[0][i % RING], rb[1], G);
+        G = VTC_MFMA(ring[1][i % RING], rb[0], G);
+      }
+      VTC_REFILL(sg, i)
+      if (overlap) epilogue_elem(p - 1, i, Gb[(p - 1) & 1], beta);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   for (int it = 0; it < P.num_iters; ++it) {
     const float beta = P.betas[it];
+    step1(0, 0, false, beta);
+    VTC_STAMP(0)
 #pragma unroll
     for (int p = 0; p < NPH; ++p) {
-      // ---- step 1: G = D[tile] R_k   (stream positions 0..15 of the phase)
-      f32x16v G;
+      if (p + 1 < NPH) {
+        step1(p + 1, 2 * p + 1, true, beta);   // + epilogue of phase p
+        VTC_STAMP(0)
+      } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) G[e] = 0.f;
-      uint4 rb_next[NP];
-#pragma unroll
-      for (int part = 0; part < NP; ++part)
-        rb_next[part] =
-            *reinterpret_cast<const uint4*>(Rx + part * kRxPart + rx_rd);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int slot = i % RING;
-        uint4 rb[NP];
-#pragma unroll
-        for (int part = 0; part < NP; ++part) {
-          rb[part] = rb_next[part];
-          if (i + 1 < 16)
-            rb_next[part] = *reinterpret_cast<const uint4*>(
-                Rx + part * kRxPart + rx_rd + 32 * (i + 1));
-        }
-        G = VTC_MFMA(ring[0][slot], rb[0], G);
-        if (NP == 2) {
-          G = VTC_MFMA(ring[0][slot], rb[1], G);
-          G = VTC_MFMA(ring[1][slot], rb[0], G);
-        }
-        const int j = i + RING;  // refill with stream position j
-#pragma unroll
-        for (int part = 0; part < NP; ++part)
-          ring[part][slot] = (j < 16)
-              ? VTC_LOAD_A(part, p, j)
-              : VTC_LOAD_T(part, p, (j - 16) & 1, (j - 16) >> 1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 16; ++e) epilogue_elem(p, e, Gb[p & 1], beta);
+        VTC_STAMP(1)
       }
-      VTC_STAMP(0)
-      // ---- proximal step + extrapolation (ista_fista.py:105-131)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 cold;
-        if (p < CREG) {
-          cold = make_float4(Cr[p < CREG ? p : 0][4 * g + 0],
-                             Cr[p < CREG ? p : 0][4 * g + 1],
-                             Cr[p < CREG ? p : 0][4 * g + 2],
-                             Cr[p < CREG ? p : 0][4 * g + 3]);
-        } else {
-          cold = *reinterpret_cast<const float4*>(
-              Cst + cst_ln + (p - CREG) * 16384 + g * 1024);
-        }
-        const float co[4] = {cold.x, cold.y, cold.z, cold.w};
-        float cn[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = 4 * g + k;
-          const float c = sub_rn(Y[p][e], mul_rn(eta, G[e]));
-          cn[k] = shrink_fast<MODE>(c, cutoff);
-          const float d = sub_rn(cn[k], co[k]);
-          Y[p][e] = add_rn(cn[k], mul_rn(beta, d));
-        }
-        if (p < CREG) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) Cr[p < CREG ? p : 0][4 * g + k] = cn[k];
-        } else {
-          *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
-                                     g * 1024) =
-              make_float4(cn[0], cn[1], cn[2], cn[3]);
-        }
-      }
-      publish_y(Y[p], p & 1);
-      VTC_STAMP(1)
       __syncthreads();
       VTC_STAMP(2)
       // ---- step 3: next residual, this wave's 64 pixels
-      step3(p, p & 1, true, (p + 1) % NPH);
+      step3(p, p & 1, true, (p + 1 < NPH) ? 2 * p + 2 : 2 * NPH - 1);
       VTC_STAMP(3)
     }
     exchange_r();
@@ -502,6 +542,10 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   }
 #undef VTC_LOAD_A
 #undef VTC_LOAD_T
+#undef VTC_LOAD_SEG
+#undef VTC_REFILL
+#undef VTC_SEG_IS_T
+#undef VTC_SEG_PHASE
 }
 
 // -------------------------------------------------------------------- host
@@ -562,7 +606,8 @@ static int launch_stamped(FusedParams P, hipStream_t st) {
                                st));
   VTC_HIP_CHECK(hipStreamSynchronize(st));
   VTC_HIP_CHECK(hipFree(dev));
-  const char* names[5] = {"step1", "epilogue", "barrier", "step3", "exchange"};
+  const char* names[5] = {"step1+epi", "epi-alone", "barrier", "step3",
+                          "exchange"};
   double total = 0;
   for (int k = 0; k < 5; ++k) total += (double)host[k];
   const double per = (double)host[7] * P.num_iters * NPH;

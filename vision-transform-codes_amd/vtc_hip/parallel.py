@@ -64,7 +64,7 @@ def all_reduce_sum_(*tensors):
   """In-place sum over ranks.  Several small tensors are packed into one flat
   buffer so that one collective (one launch latency) covers them: at 1 MiB the
   exchange is latency-bound on xGMI, not bandwidth-bound."""
-  if not is_enabled() or world_size() == 1:
+  if not is_enabled():
     return
   if len(tensors) == 1:
     dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, group=_group)
