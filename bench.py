@@ -187,6 +187,16 @@ def main():
   flops_per_launch = batch * FISTA_ITERS * FLOP_PER_PATCH_ITER
   achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
   peak = PEAK_TFLOPS[precision]
+  # HBM bytes per launch from the PMC passes committed under profiles/
+  # (rocprofv3 cannot run inside this process); only quoted when it was
+  # measured for this very precision and batch
+  traffic = None
+  try:
+    measured = json.load(open(REPO / 'profiles' / 'r01_hbm_traffic.json'))
+    if measured.get('batch') == batch and precision in measured:
+      traffic = measured[precision]['hbm_bytes_per_launch']
+  except (OSError, ValueError):
+    pass
   result = {
       'metric': 'patches/sec through 200-iter FISTA + dict update, '
                 '1024-atom dict',
@@ -205,7 +215,7 @@ def main():
           'bound': 'mfma',
           'kernel': KERNEL_NAMES[precision],
           'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-          'frac': achieved / peak, 'traffic': None,
+          'frac': achieved / peak, 'traffic': traffic,
           'ms_per_launch': kernel_ms,
           'flops_per_launch': flops_per_launch,
           'note': 'algorithmic flops 4*s*n per patch-iteration; bf16x3 issues '
