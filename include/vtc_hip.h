@@ -82,6 +82,13 @@ int vtc_abi_version(void);
  * second on the (s, c*kh*kw) flattened kernels. */
 int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
              float* gram, void* stream);
+/* Largest eigenvalue of a symmetric (n,n) matrix, n <= 256, replacing the
+ * `torch.symeig(...)[0][-1]` of ista_fista.py:73-74: single-workgroup Lanczos
+ * with full re-orthogonalisation + Sturm bisection.  out (device, 2 floats) =
+ * [lambda_max, 1/lambda_max].  Larger n: VTC_ERR_UNSUPPORTED (the caller then
+ * uses a library eigen-solver). */
+int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
+                   void* stream);
 
 /* ---- fully-connected inference (row a1) ------------------------------- */
 size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n, int64_t s,

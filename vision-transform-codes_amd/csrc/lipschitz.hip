@@ -1,0 +1,203 @@
+// Largest eigenvalue of a small symmetric matrix on the device.
+//
+// The reference takes the ISTA/FISTA step size from
+//   torch.symeig(D^T D)[0][-1]        (ista_fista.py:72-80, and the subspace /
+//                                      convolutional variants)
+// once per plugin call, i.e. once per training step.  A full rocSOLVER
+// eigen-decomposition of a 256 x 256 matrix costs ~4 ms on MI355X (measured:
+// 5 % of a whole training step).  Only the top eigenvalue is needed, so this is a
+// single-workgroup Lanczos iteration with full re-orthogonalisation (the
+// Krylov basis lives in LDS), followed by bisection on the tridiagonal
+// matrix with Sturm counts, in double precision, on one lane.  For n <= 128
+// the Krylov space is the whole space and the result is the exact top
+// eigenvalue up to rounding; for n <= 256, 128 steps converge to f32
+// resolution on the spectra of interest (extreme eigenvalue, Kaniel-Paige).
+#include "common.h"
+
+namespace vtc {
+
+constexpr int kLanczosMaxN = 256;
+constexpr int kLanczosMaxK = 128;
+
+constexpr int kLanczosThreads = 1024;   // 16 waves: 4 per SIMD
+constexpr int kLanczosParts = 4;        // row ranges of the mat-vec
+
+// sum over the first 256 threads (the vector components); every thread of the
+// block calls this and receives the result
+__device__ __forceinline__ double block_sum_vec(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Thread layout: tid = part * 256 + t.  Component t of every vector belongs
+// to the threads (.., t); part 0 owns the Lanczos recurrences, parts 1..3 only
+// help with the mat-vec and the Gram-Schmidt sums.
+__global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
+    const float* __restrict__ G, int n, int k, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* V = lds;                         // [k][n] Krylov basis
+  float* wl = V + (size_t)k * n;          // [n] work vector
+  float* coef = wl + n;                   // [k]
+  float* partial = coef + k;              // [parts][256]
+  __shared__ double red[4];
+  __shared__ double alpha[kLanczosMaxK];
+  __shared__ double beta[kLanczosMaxK];
+  __shared__ int steps_done;
+  const int tid = threadIdx.x;
+  const int t = tid & 255, part = tid >> 8;
+  const int lane = tid & 63, wave = tid >> 6;   // 16 waves
+  const bool on = t < n;
+  const bool owner = (part == 0) && on;
+
+  // deterministic, generic start vector
+  float v = 0.f;
+  if (owner) {
+    unsigned x = (unsigned)t * 2654435761u + 12345u;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    v = 0.5f + (float)(x & 0xffff) / 65536.f;
+  }
+  double nrm = sqrt(block_sum_vec((double)v * v, red));
+  v = (float)(v / nrm);
+  float v_prev = 0.f;
+  double beta_prev = 0.0;
+  if (tid == 0) steps_done = k;
+  const int rows_per_part = (n + kLanczosParts - 1) / kLanczosParts;
+  const int i0 = part * rows_per_part;
+  const int i1 = (i0 + rows_per_part < n) ? i0 + rows_per_part : n;
+  __syncthreads();
+
+  for (int j = 0; j < k; ++j) {
+    if (owner) V[(size_t)j * n + t] = v;
+    __syncthreads();
+    // w = G v  (G symmetric: "column" t is contiguous across threads); each
+    // part sums its row range with 4 independent accumulators
+    {
+      const float* vj = V + (size_t)j * n;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (on) {
+        int i = i0;
+        for (; i + 3 < i1; i += 4) {
+          a0 = fmaf(G[(size_t)(i + 0) * n + t], vj[i + 0], a0);
+          a1 = fmaf(G[(size_t)(i + 1) * n + t], vj[i + 1], a1);
+          a2 = fmaf(G[(size_t)(i + 2) * n + t], vj[i + 2], a2);
+          a3 = fmaf(G[(size_t)(i + 3) * n + t], vj[i + 3], a3);
+        }
+        for (; i < i1; ++i) a0 = fmaf(G[(size_t)i * n + t], vj[i], a0);
+      }
+      partial[part * 256 + t] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    float w = 0.f;
+    if (owner)
+      w = (partial[t] + partial[256 + t]) + (partial[512 + t] + partial[768 + t]);
+    const double a = block_sum_vec(owner ? (double)w * v : 0.0, red);
+    if (owner) {
+      w = w - (float)a * v - (float)beta_prev * v_prev;
+      wl[t] = w;
+    }
+    __syncthreads();
+    // full re-orthogonalisation against V[0..j]: coefficients by 16 waves,
+    // correction split over the 4 parts
+    for (int i = wave; i <= j; i += kLanczosThreads / 64) {
+      float p = 0.f;
+      for (int c = lane; c < n; c += 64) p = fmaf(V[(size_t)i * n + c], wl[c], p);
+      p = wave_sum(p);
+      if (lane == 0) coef[i] = p;
+    }
+    __syncthreads();
+    {
+      float corr = 0.f;
+      if (on)
+        for (int i = part; i <= j; i += kLanczosParts)
+          corr = fmaf(coef[i], V[(size_t)i * n + t], corr);
+      partial[part * 256 + t] = corr;
+    }
+    __syncthreads();
+    if (owner)
+      w -= (partial[t] + partial[256 + t]) + (partial[512 + t] + partial[768 + t]);
+    const double b = sqrt(block_sum_vec(owner ? (double)w * w : 0.0, red));
+    if (tid == 0) {
+      alpha[j] = a;
+      beta[j] = b;
+    }
+    // invariant subspace reached (or a NaN): the tridiagonal matrix so far
+    // already holds the spectrum of the reachable space
+    if (!(b > 1e-7 * fabs(a) + 1e-30)) {
+      if (tid == 0) steps_done = j + 1;
+      break;
+    }
+    v_prev = v;
+    v = (float)(w / b);
+    beta_prev = b;
+  }
+  __syncthreads();
+
+  if (tid == 0) {
+    const int m = steps_done;
+    // Gershgorin bounds of the tridiagonal matrix
+    double lo = alpha[0], hi = alpha[0];
+    for (int i = 0; i < m; ++i) {
+      const double off = (i > 0 ? fabs(beta[i - 1]) : 0.0) +
+                         (i + 1 < m ? fabs(beta[i]) : 0.0);
+      lo = fmin(lo, alpha[i] - off);
+      hi = fmax(hi, alpha[i] + off);
+    }
+    double lambda;
+    if (!(hi == hi) || !(lo == lo)) {
+      lambda = hi + lo;  // NaN propagates to the caller
+    } else {
+      // largest eigenvalue: smallest x with (#eigenvalues < x) == m
+      for (int it = 0; it < 200 && hi - lo > 1e-14 * fmax(fabs(hi), fabs(lo));
+           ++it) {
+        const double x = 0.5 * (lo + hi);
+        int below = 0;
+        double d = 1.0;
+        for (int i = 0; i < m; ++i) {
+          const double off2 = (i > 0) ? beta[i - 1] * beta[i - 1] : 0.0;
+          d = (alpha[i] - x) - (i > 0 ? off2 / d : 0.0);
+          if (d == 0.0) d = -1e-300;
+          if (d < 0.0) ++below;
+        }
+        if (below == m) hi = x; else lo = x;
+      }
+      lambda = 0.5 * (lo + hi);
+    }
+    const float lf = (float)lambda;
+    out[0] = lf;
+    out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+  }
+}
+
+}  // namespace vtc
+
+using namespace vtc;
+
+// out: 2 floats on the device: [lambda_max, 1/lambda_max]
+extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
+                              void* stream) {
+  VTC_REQUIRE(symmetric && out, "vtc_lambda_max: null pointer");
+  VTC_REQUIRE(n > 0, "vtc_lambda_max: bad size");
+  if (n > kLanczosMaxN) {
+    set_error("vtc_lambda_max: n = %lld exceeds the single-workgroup Lanczos "
+              "limit of %d", (long long)n, kLanczosMaxN);
+    return VTC_ERR_UNSUPPORTED;
+  }
+  const int k = (int)(n < kLanczosMaxK ? n : kLanczosMaxK);
+  const size_t lds =
+      ((size_t)k * n + n + k + kLanczosParts * 256) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(lanczos_lambda_max_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    configured = true;
+  }
+  hipLaunchKernelGGL(lanczos_lambda_max_kernel, dim3(1),
+                     dim3(kLanczosThreads), lds,
+                     as_stream(stream), symmetric, (int)n, k, out);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}

@@ -54,6 +54,7 @@ SIGNATURES = {
     'vtc_last_error': (ctypes.c_char_p, []),
     'vtc_abi_version': (_i32, []),
     'vtc_gram': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'vtc_lambda_max': (_i32, [_vp, _i64, _vp, _vp]),
     'vtc_fc_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i32]),
     'vtc_fc_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                  _f32, _i32, _i32, _i32, _f32, _i32, _vp, _sz,
@@ -230,17 +231,37 @@ def gram(matrix, transpose_a):
   return out
 
 
+LANCZOS_MAX_N = 256
+_use_device_eigensolver = os.environ.get('VTC_EIGEN', 'lanczos') != 'library'
+
+
 def stepsize_from_gram(gram_matrix, dictionary_for_message):
-  """eta = 1 / lambda_max.  The eigen-solve is the library call the reference
-  also delegates to (torch.symeig there, removed in torch>=2; eigvalsh is its
-  successor).  Mirrors the reference's error path: print the kernel norms and
-  raise a bare RuntimeError (ista_fista.py:75-79)."""
+  """eta = 1 / lambda_max(gram) as a Python float.
+
+  n <= 256: vtc_lambda_max (one small HIP kernel: Lanczos + bisection).
+  Otherwise torch.linalg.eigvalsh, the successor of the torch.symeig the
+  reference calls (removed in torch >= 2).  Mirrors the reference's error
+  path: on failure print the kernel norms and raise a bare RuntimeError
+  (ista_fista.py:75-79)."""
+  n = gram_matrix.shape[0]
   try:
+    if _use_device_eigensolver and n <= LANCZOS_MAX_N:
+      lib = load_library()
+      out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
+      check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out),
+                               current_stream(gram_matrix.device)),
+            'vtc_lambda_max')
+      lipschitz_constant, stepsize = [float(v) for v in out.tolist()]
+      if not (lipschitz_constant == lipschitz_constant) or (
+          lipschitz_constant in (float('inf'), float('-inf'))):
+        raise RuntimeError('non-finite spectrum')
+      return stepsize
     lipschitz_constant = torch.linalg.eigvalsh(gram_matrix, UPLO='U')[-1]
   except RuntimeError:
-    print('eigvalsh threw an exception. Likely due to one of the dictionary',
-          'elements overflowing. The norm of each dictionary element is')
+    print('the eigen-solve threw an exception. Likely due to one of the',
+          'dictionary elements overflowing. The norm of each dictionary',
+          'element is')
     flat = dictionary_for_message.reshape(dictionary_for_message.shape[0], -1)
     print(torch.norm(flat, dim=1, p=2))
     raise RuntimeError()
-  return 1. / lipschitz_constant
+  return float(1. / lipschitz_constant)
