@@ -144,3 +144,20 @@ def test_unsupported_shapes_fall_back_or_raise(device, ista_fista):
   auto = ista_fista.run(X, D, 0.05, 5, precision='auto', stepsize=0.3)
   f32 = ista_fista.run(X, D, 0.05, 5, precision='f32', stepsize=0.3)
   assert torch.equal(auto, f32)
+
+
+def test_lds_staged_variant_is_bit_identical(device, ista_fista, monkeypatch):
+  """VTC_FUSED_VARIANT=2 (dictionary staged once per iteration through LDS by
+  LDS-DMA, transposed reads with ds_read_b64_tr_b16) computes exactly the same
+  arithmetic as the default register-ring variant."""
+  g, X, D, lam, eta = _c2(device)
+  ref = ista_fista.run(X, D, lam, 60, precision='bf16', stepsize=eta)
+  monkeypatch.setenv('VTC_FUSED_VARIANT', '2')
+  out = ista_fista.run(X, D, lam, 60, precision='bf16', stepsize=eta)
+  warm = ista_fista.run(X, D, lam, 5, precision='bf16', stepsize=eta,
+                        initial_codes=out)
+  monkeypatch.delenv('VTC_FUSED_VARIANT')
+  warm_ref = ista_fista.run(X, D, lam, 5, precision='bf16', stepsize=eta,
+                            initial_codes=ref)
+  assert torch.equal(out, ref)
+  assert torch.equal(warm, warm_ref)

@@ -548,6 +548,303 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
 #undef VTC_SEG_PHASE
 }
 
+// ===========================================================================
+// Variant 2 (bf16): the dictionary goes through LDS once per iteration.
+//
+// In the kernel above every dictionary byte reaches the CU twice per
+// iteration (row-wise fragments for step 1, transposed fragments for step 3),
+// and both MFMA phases run at the per-CU vector-memory rate (64 B/clk) rather
+// than at the MFMA rate (in-kernel stamps, profiles/r01_fused_stamps.txt).
+// Here a phase's 128 x 256 bf16 block (64 KiB) is copied ONCE by LDS-DMA
+// (global_load_lds_dwordx4, no VGPRs) into one of two LDS buffers; step 1 reads
+// its A fragments from it by rows (ds_read_b128) and step 3 reads the SAME image
+// transposed (ds_read_b64_tr_b16).  The global copy is pre-packed as the exact
+// LDS image, XOR-swizzled so that both read patterns are bank-conflict free:
+//   element (atom row r of the phase, pixel x) -> byte
+//   r*512 + (((x>>3) ^ f(r)) << 4) + (x&7)*2,   f(r) = 4*(r&3) + ((r>>3)&3)
+// With the LDS holding 2 x 64 KiB of dictionary the previous codes C move from
+// LDS to VGPRs (Y and C: 256 VGPRs per lane); the register ring disappears.
+// Two barriers per phase: after the epilogue (Y' published) and after step 3
+// (buffer and exchange area free; the barrier also drains the DMA issued one
+// phase ahead).
+// ===========================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__global__ void pack_lds_image_kernel(const float* __restrict__ D, int s,
+                                      __bf16* __restrict__ image) {
+  const int64_t chunks = (int64_t)s * kFN / 8;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < chunks;
+       u += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(u & 31);          // 8-pixel chunk of the row
+    const int64_t atom = u >> 5;
+    const int rl = (int)(atom & 127);     // row inside the phase
+    const int f = 4 * (rl & 3) + ((rl >> 3) & 3);
+    const float* src = D + atom * kFN + 8 * c;
+    __bf16* dst = image + (atom >> 7) * 32768 + (int64_t)rl * 256 +
+                  ((c ^ f) << 3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = (__bf16)src[j];
+  }
+}
+
+constexpr int kDbufBytes = 65536;
+constexpr int kLdsV2Total = 2 * kDbufBytes + kYxPart + kRxPart;  // 156672
+
+template <int NPH, int MODE, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void fused_fista_lds_kernel(
+    FusedParams P) {
+  static_assert(NPH % 2 == 0, "buffer parity must continue across iterations");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Dbuf = smem;
+  char* Yx = smem + 2 * kDbufBytes;
+  char* Rx = Yx + kYxPart;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t patch = (int64_t)blockIdx.x * kFP + r;
+  const bool live = patch < P.b;
+  const int s = P.s;
+
+  // LDS lane bases (exchange areas as in the kernel above)
+  const int yx_rd = r * kYxRow + 16 * h;
+  const int yx_wr = r * kYxRow + 64 * w + 8 * h;
+  const int rx_rd = r * kRxRow + 16 * h;
+  const int rx_wr = r * kRxRow + 128 * w + 8 * h;
+  // step-1 row reads: row 32w + r of the phase image, chunk (2ks + h) ^ fR
+  const int fR = 4 * (r & 3) + ((r >> 3) & 3);
+  const int a_row = (32 * w + r) * 512;
+  // step-3 transposed reads: lane (rho, pi) of 16-lane group g16
+  const int rho = (lane & 15) >> 2, pi = lane & 3, g16 = (lane >> 4) & 1;
+  const int t_lane_chunk = ((pi >> 1) ^ h) | (g16 << 1) | ((rho & 1) << 2) |
+                           (((w & 1) ^ (rho >> 1)) << 3) | ((w >> 1) << 4);
+  const int t_row = (8 * h + rho) * 512 + 8 * (pi & 1);
+
+  // LDS-DMA through a buffer descriptor: one VGPR (lane * 16) for every copy,
+  // the piece address as a scalar offset.  (With flat pointers hipcc
+  // pre-computes a 64-bit VGPR address per piece and keeps all 16 * NPH of
+  // them live across the iteration loop.)
+  const __amdgpu_buffer_rsrc_t image_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)P.packA[0], 0, (int)((unsigned)s * kFN * 2u), 0x00020000);
+  const int dma_voff = lane * 16;
+  const int dma_wave = w * 16384;
+  // one phase = 64 pieces of 1 KiB; wave w copies pieces 16w .. 16w+15
+  auto dma_piece = [&](int p, int buf, int i) {
+    char* dst = Dbuf + buf * kDbufBytes + dma_wave;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        image_rsrc, (lds_void*)(dst + i * 1024), 16, dma_voff,
+        p * kDbufBytes + dma_wave + i * 1024, 0, 0);
+  };
+  auto dma_phase = [&](int p, int buf) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dma_piece(p, buf, i);
+  };
+
+  f32x16v Y[NPH], C[NPH], Xr[2], Racc[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live)
+        v = *reinterpret_cast<const float4*>(
+            P.images + patch * kFN + 64 * w + 32 * nb + 8 * g + 4 * h);
+      Xr[nb][4 * g + 0] = v.x;
+      Xr[nb][4 * g + 1] = v.y;
+      Xr[nb][4 * g + 2] = v.z;
+      Xr[nb][4 * g + 3] = v.w;
+    }
+  }
+  const bool warm = (P.init != nullptr);
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (warm && live)
+        v = *reinterpret_cast<const float4*>(
+            P.init + patch * s + kPhaseAtoms * p + 32 * w + 8 * g + 4 * h);
+      Y[p][4 * g + 0] = C[p][4 * g + 0] = v.x;
+      Y[p][4 * g + 1] = C[p][4 * g + 1] = v.y;
+      Y[p][4 * g + 2] = C[p][4 * g + 2] = v.z;
+      Y[p][4 * g + 3] = C[p][4 * g + 3] = v.w;
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
+
+  auto publish_y = [&](const f32x16v& y) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 hi;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hi[k] = (__bf16)y[4 * g + k];
+      *reinterpret_cast<uint2*>(Yx + yx_wr + 16 * g) =
+          __builtin_bit_cast(uint2, hi);
+    }
+  };
+
+  // step 3 from LDS buffer `buf`: Racc[nb] += D^T (transposed reads) x Y'.
+  // Operands are read one MFMA ahead; the sched_barrier per MFMA keeps hipcc
+  // from hoisting all 48 LDS reads of the step to its top (register blow-up).
+  auto tr_frag = [&](const char* base, int ks, int nb) {
+    const int kconst = ((ks & 1) << 1) | (nb << 2);
+    const int off = ((t_lane_chunk ^ kconst) << 4);
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(base + off +
+                                                   (16 * ks + 0) * 512));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(base + off +
+                                                   (16 * ks + 4) * 512));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo4);
+    const uint2 h2 = __builtin_bit_cast(uint2, hi4);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  };
+  auto step3 = [&](int buf, int next_p, bool prefetch) {
+    const char* base = Dbuf + buf * kDbufBytes + t_row;
+    uint4 a_next = tr_frag(base, 0, 0);
+    uint4 yb_next = *reinterpret_cast<const uint4*>(Yx + yx_rd);
+    uint4 yb = yb_next;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ks = i >> 1, nb = i & 1;
+      const uint4 a = a_next;
+      if (nb == 0) {
+        yb = yb_next;
+        if (ks + 1 < 8)
+          yb_next =
+              *reinterpret_cast<const uint4*>(Yx + yx_rd + 32 * (ks + 1));
+      }
+      if (i + 1 < 16) a_next = tr_frag(base, (i + 1) >> 1, (i + 1) & 1);
+      Racc[nb] = VTC_MFMA(a, yb, Racc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto exchange_r = [&]() {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          hi[k] = (__bf16)sub_rn(Racc[nb][4 * g + k], Xr[nb][4 * g + k]);
+        *reinterpret_cast<uint2*>(Rx + rx_wr + 64 * nb + 16 * g) =
+            __builtin_bit_cast(uint2, hi);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
+    __syncthreads();
+  };
+
+  // ---- R_0 = Y_0 D - X ---------------------------------------------------
+  if (warm) {
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      dma_phase(p, p & 1);
+      publish_y(Y[p]);
+      __syncthreads();          // drains the DMA, publishes Y'
+      step3(p & 1, 0, false);
+      __syncthreads();
+    }
+  }
+  exchange_r();
+  dma_phase(0, 0);
+  __syncthreads();
+
+  const float eta = P.eta, cutoff = P.cutoff;
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+  unsigned long long t0 = 0, t1 = 0;
+#define VTC_STAMP(slot)                    \
+  if (STAMP) {                             \
+    t1 = stamp_now();                      \
+    acc_t[slot] += t1 - t0;                \
+    t0 = t1;                               \
+  }
+  if (STAMP) t0 = stamp_now();
+  for (int it = 0; it < P.num_iters; ++it) {
+    const float beta = P.betas[it];
+#pragma unroll
+    for (int p = 0; p < NPH; ++p) {
+      // prefetch the next phase into the other buffer (free since the barrier
+      // that closed the previous phase).  Measured on MI355X: a 1 KiB LDS-DMA
+      // piece costs the issuing wave ~200 cycles wherever it is placed (as one
+      // burst here: step 1 = 2186 cycles; sprinkled between the MFMAs of
+      // step 1 / step 3: 2255 / 1481), i.e. the LDS-DMA path delivers less
+      // than the plain buffer loads of the register-ring variant, which is why
+      // this variant is not the default.
+      dma_phase((p + 1) % NPH, (p + 1) & 1);
+      // ---- step 1: G = D[tile] R_k, A fragments by rows from LDS
+      f32x16v G;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) G[e] = 0.f;
+      const char* abase = Dbuf + (p & 1) * kDbufBytes + a_row;
+      uint4 a_next =
+          *reinterpret_cast<const uint4*>(abase + (((0 + h) ^ fR) << 4));
+      uint4 rb_next = *reinterpret_cast<const uint4*>(Rx + rx_rd);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint4 a = a_next, rb = rb_next;
+        if (i + 1 < 16) {
+          a_next = *reinterpret_cast<const uint4*>(
+              abase + (((2 * (i + 1) + h) ^ fR) << 4));
+          rb_next =
+              *reinterpret_cast<const uint4*>(Rx + rx_rd + 32 * (i + 1));
+        }
+        G = VTC_MFMA(a, rb, G);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      VTC_STAMP(0)
+      // ---- proximal step + extrapolation (ista_fista.py:105-131)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float c = sub_rn(Y[p][e], mul_rn(eta, G[e]));
+        const float cn = shrink_fast<MODE>(c, cutoff);
+        const float d = sub_rn(cn, C[p][e]);
+        Y[p][e] = add_rn(cn, mul_rn(beta, d));
+        C[p][e] = cn;
+      }
+      publish_y(Y[p]);
+      VTC_STAMP(1)
+      // Y' visible to the other waves; LDS writes only, the DMA stays in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      VTC_STAMP(2)
+      step3(p & 1, (p + 1) % NPH, true);
+      VTC_STAMP(3)
+      __syncthreads();   // buffer p&1 and Yx free; next phase's DMA landed
+      VTC_STAMP(2)
+    }
+    exchange_r();
+    VTC_STAMP(4)
+  }
+  if (STAMP && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) atomicAdd(P.stamps + k, acc_t[k]);
+    atomicAdd(P.stamps + 7, 1ull);
+  }
+#undef VTC_STAMP
+
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (live)
+        *reinterpret_cast<float4*>(P.codes + patch * s + kPhaseAtoms * p +
+                                   32 * w + 8 * g + 4 * h) =
+            make_float4(C[p][4 * g + 0], C[p][4 * g + 1], C[p][4 * g + 2],
+                        C[p][4 * g + 3]);
+    }
+  }
+}
+
 // -------------------------------------------------------------------- host
 static int phases_for(int64_t s) { return (int)(s / kPhaseAtoms); }
 
@@ -629,6 +926,73 @@ static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
   }
 }
 
+// ---- variant 2 (LDS-staged dictionary, bf16) ------------------------------
+static void print_stamps(const unsigned long long* host, int num_iters,
+                         int nph, const char* const* names) {
+  double total = 0;
+  for (int k = 0; k < 5; ++k) total += (double)host[k];
+  const double per = (double)host[7] * num_iters * nph;
+  for (int k = 0; k < 5; ++k)
+    fprintf(stderr, "[vtc stamps] %-9s %5.1f%%  %8.0f cycles/phase/wave\n",
+            names[k], 100.0 * host[k] / total, host[k] / per);
+}
+
+template <int NPH, int MODE, bool STAMP>
+static int launch_lds(FusedParams P, hipStream_t st) {
+  auto kernel = fused_fista_lds_kernel<NPH, MODE, STAMP>;
+  static bool configured = false;
+  if (!configured) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsV2Total));
+    configured = true;
+  }
+  unsigned long long* dev = nullptr;
+  if (STAMP) {
+    VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
+    VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
+    P.stamps = dev;
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
+                     kLdsV2Total, st, P);
+  VTC_LAUNCH_CHECK();
+  if (STAMP) {
+    unsigned long long host[8];
+    VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host),
+                                 hipMemcpyDeviceToHost, st));
+    VTC_HIP_CHECK(hipStreamSynchronize(st));
+    VTC_HIP_CHECK(hipFree(dev));
+    const char* names[5] = {"step1", "epilogue", "barriers", "step3",
+                            "exchange"};
+    print_stamps(host, P.num_iters, NPH, names);
+  }
+  return VTC_OK;
+}
+
+template <int NPH>
+static int dispatch_lds_mode(const FusedParams& P, int threshold,
+                             hipStream_t st) {
+  if (threshold == VTC_SOFT && getenv("VTC_FUSED_STAMPS"))
+    return launch_lds<NPH, VTC_SOFT, true>(P, st);
+  switch (threshold) {
+    case VTC_SOFT: return launch_lds<NPH, VTC_SOFT, false>(P, st);
+    case VTC_SOFT_NONNEG:
+      return launch_lds<NPH, VTC_SOFT_NONNEG, false>(P, st);
+    case VTC_HARD: return launch_lds<NPH, VTC_HARD, false>(P, st);
+    default: return launch_lds<NPH, VTC_HARD_NONNEG, false>(P, st);
+  }
+}
+
+static int dispatch_lds(const FusedParams& P, int threshold, hipStream_t st) {
+  switch (phases_for(P.s)) {
+    case 2: return dispatch_lds_mode<2>(P, threshold, st);
+    case 4: return dispatch_lds_mode<4>(P, threshold, st);
+    case 8: return dispatch_lds_mode<8>(P, threshold, st);
+  }
+  set_error("fused FISTA: unsupported atom count %d", P.s);
+  return VTC_ERR_UNSUPPORTED;
+}
+
 template <int NP>
 static int dispatch_phases(const FusedParams& P, int threshold,
                            hipStream_t st) {
@@ -668,11 +1032,23 @@ int run_fused(const float* images, const float* dictionary,
     packs[2 * part + 1] = ws.take<__bf16>((size_t)s * kFN);
   }
   float* betas_dev = ws.take<float>(4096);
-  for (int part = 0; part < parts; ++part) {
-    hipLaunchKernelGGL(pack_dictionary_kernel, dim3(256), dim3(256), 0, st,
-                       dictionary, (int)s, packs[2 * part],
-                       packs[2 * part + 1], part);
+  // bf16: VTC_FUSED_VARIANT=2 selects the experimental LDS-staged variant
+  // (same results bit for bit; slower on MI355X, see its header); the
+  // register-ring variant is the default and the only one for bf16x3
+  const char* variant_env = getenv("VTC_FUSED_VARIANT");
+  const bool use_lds_variant =
+      (parts == 1) && variant_env && variant_env[0] == '2';
+  if (use_lds_variant) {
+    hipLaunchKernelGGL(pack_lds_image_kernel, dim3(256), dim3(256), 0, st,
+                       dictionary, (int)s, packs[0]);
     VTC_LAUNCH_CHECK();
+  } else {
+    for (int part = 0; part < parts; ++part) {
+      hipLaunchKernelGGL(pack_dictionary_kernel, dim3(256), dim3(256), 0, st,
+                         dictionary, (int)s, packs[2 * part],
+                         packs[2 * part + 1], part);
+      VTC_LAUNCH_CHECK();
+    }
   }
   // ISTA is FISTA with beta = 0: y = c + 0 * (c - c_prev) = c exactly
   std::vector<float> betas;
@@ -700,8 +1076,9 @@ int run_fused(const float* images, const float* dictionary,
   P.eta = eta;
   P.cutoff = cutoff;
   P.stamps = nullptr;
-  int rc = (parts == 2) ? dispatch_phases<2>(P, threshold, st)
-                        : dispatch_phases<1>(P, threshold, st);
+  int rc = use_lds_variant ? dispatch_lds(P, threshold, st)
+           : (parts == 2)  ? dispatch_phases<2>(P, threshold, st)
+                           : dispatch_phases<1>(P, threshold, st);
   if (rc == VTC_OK && iters_run) *iters_run = num_iters;
   return rc;
 }
