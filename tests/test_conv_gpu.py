@@ -103,3 +103,38 @@ def test_geometry_mismatch_is_an_error(device, plugins):
   D = torch.ones(2, 1, 6, 6, device=device)
   with pytest.raises(ValueError):
     conv.run(imgs, D, (4, 4), ((2, 4), (2, 4)), 0.1, 2, stepsize=0.1)
+
+
+@pytest.mark.parametrize('k,c,s,height,width', [(5, 2, 6, 70, 93),
+                                                (8, 1, 5, 41, 130),
+                                                (16, 1, 3, 48, 80),
+                                                (11, 3, 9, 64, 64)])
+def test_unit_stride_specialisations(device, plugins, k, c, s, height, width):
+  """Stride-1 square kernels take the scalar-tap kernels of conv_unit.h:
+  sizes that do not divide the 32x64 tile, kernel counts that do not divide
+  the chunk of 4, several channels, padding frame -- against the oracle."""
+  conv, steepest, _ = plugins
+  rs = np.random.RandomState(1000 + k)
+  pad = k - 1
+  imgs = np.zeros((2, c, height + 2 * pad, width + 2 * pad), np.float32)
+  imgs[:, :, pad:pad + height, pad:pad + width] = (
+      0.5 * rs.randn(2, c, height, width)).astype(np.float32)
+  D = rs.randn(s, c, k, k).astype(np.float32)
+  D /= np.sqrt((D.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[
+      :, None, None, None].astype(np.float32)
+  padding = ((pad, pad), (pad, pad))
+  eta = sc_oracle.conv_stepsize(torch.from_numpy(D))
+  ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D),
+                                  (1, 1), padding, 0.05, 8, stepsize=eta)
+  codes = conv.run(helpers.to_dev(imgs, device), helpers.to_dev(D, device),
+                   (1, 1), padding, 0.05, 8, stepsize=float(eta))
+  helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), 2e-5,
+                             'unit stride k=%d' % k, max_flip_mag=1e-5)
+  refD = torch.from_numpy(D.copy())
+  sc_oracle.conv_steepest_descent(torch.from_numpy(imgs), refD, ref, (1, 1),
+                                  padding, stepsize=0.005)
+  Dg = helpers.to_dev(D.copy(), device)
+  steepest.run(helpers.to_dev(imgs, device), Dg,
+               helpers.to_dev(ref.numpy(), device), (1, 1), padding,
+               stepsize=0.005)
+  assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6

@@ -51,7 +51,7 @@ def subspace(dev):
 def conv(dev):
   from analysis_transforms.convolutional import ista_fista
   from dict_update_rules.convolutional import sc_steepest_descent
-  b, s, k, img, iters = 4, 128, 11, 256, 20
+  b, s, k, img, iters = 8, 128, 11, 256, 20
   pad = k - 1
   rs = np.random.RandomState(0)
   X = np.zeros((b, 1, img + 2 * pad, img + 2 * pad), np.float32)

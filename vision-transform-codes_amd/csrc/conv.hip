@@ -211,6 +211,10 @@ struct ProxParams {
   double* delta_sum;
 };
 
+}  // namespace vtc
+#include "conv_unit.h"
+namespace vtc {
+
 __global__ __launch_bounds__(256) void conv_analysis_prox_kernel(
     const float* __restrict__ residual, const float* __restrict__ Kt,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tp, int tq,
@@ -427,7 +431,8 @@ static size_t conv_inference_ws(const ConvGeo& g) {
   const size_t code_elems = (size_t)g.b * g.s * g.ch * g.cw;
   const size_t img_elems = (size_t)g.b * g.c * g.H * g.W;
   return align_up(code_elems * sizeof(float), 256) +          // Y
-         align_up(img_elems * sizeof(float), 256) +           // residual
+         align_up(8 * img_elems * sizeof(float), 256) +       // residual or
+                                                              // <= 8 partials
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
          256;
 }
@@ -435,6 +440,8 @@ static size_t conv_inference_ws(const ConvGeo& g) {
 static int launch_synthesis(const float* codes, const float* D,
                             const float* images, float* residual,
                             const ConvGeo& g, hipStream_t st) {
+  if (unit_geometry(g))
+    return launch_synth_unit(codes, D, images, residual, g, 1, g.s, st);
   const SynPlan sp = plan_synthesis(g);
   const int tiles_x = (int)ceil_div(g.W, kSynTile);
   const int tiles_y = (int)ceil_div(g.H, kSynTile);
@@ -500,7 +507,7 @@ extern "C" int vtc_conv_ista_fista(
   const int ctaps = g.c * g.kh * g.kw;
   Carver ws(workspace);
   float* Ybuf = ws.take<float>(code_elems);
-  float* residual = ws.take<float>(img_elems);
+  float* residual = ws.take<float>(8 * img_elems);
   float* Kt = ws.take<float>((size_t)g.s * ctaps);
   double* delta_sum = ws.take<double>(1);
   const bool fista = (variant == VTC_FISTA);
@@ -524,6 +531,13 @@ extern "C" int vtc_conv_ista_fista(
   const AnaPlan ap = plan_analysis(g);
   const int tiles_p = (int)ceil_div(g.ch, ap.tp);
   const int tiles_q = (int)ceil_div(g.cw, ap.tq);
+  const bool unit_path = unit_geometry(g) && unit_analysis_fits(g);
+  int syn_per_group = g.s;
+  const int syn_groups =
+      unit_path ? unit_groups(g, (int)(ceil_div(g.W, kUnitTX) *
+                                       ceil_div(g.H, kUnitTY)),
+                              &syn_per_group)
+                : 1;
   const float eta = stepsize;
   const float cutoff = sparsity_weight * stepsize;
   const float eps = early_stopping_epsilon;
@@ -531,17 +545,28 @@ extern "C" int vtc_conv_ista_fista(
   fista_betas(num_iters, &betas);
   int done = 0;
   for (int k = 0; k < num_iters; ++k) {
-    rc = launch_synthesis(Y, dictionary, images_padded, residual, g, st);
-    if (rc != VTC_OK) return rc;
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     ProxParams pp{eta, cutoff, fista ? betas[k] : 0.f, threshold,
                   fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr};
-    hipLaunchKernelGGL(conv_analysis_prox_kernel,
-                       dim3((unsigned)(tiles_p * tiles_q), (unsigned)g.b),
-                       dim3(256), ap.lds_bytes, st, residual, Kt, Y, codes, g,
-                       ap.tp, ap.tq, ap.wy, ap.wx, tiles_q, pp);
-    VTC_LAUNCH_CHECK();
+    if (unit_path) {
+      // stride-1 square kernels: scalar-tap kernels, the kernel sum of the
+      // synthesis split over `syn_groups` blocks per tile
+      rc = launch_synth_unit(Y, dictionary, images_padded, residual, g,
+                             syn_groups, syn_per_group, st);
+      if (rc != VTC_OK) return rc;
+      rc = launch_analysis_unit(residual, images_padded, syn_groups,
+                                dictionary, Y, codes, g, pp, st);
+      if (rc != VTC_OK) return rc;
+    } else {
+      rc = launch_synthesis(Y, dictionary, images_padded, residual, g, st);
+      if (rc != VTC_OK) return rc;
+      hipLaunchKernelGGL(conv_analysis_prox_kernel,
+                         dim3((unsigned)(tiles_p * tiles_q), (unsigned)g.b),
+                         dim3(256), ap.lds_bytes, st, residual, Kt, Y, codes,
+                         g, ap.tp, ap.tq, ap.wy, ap.wx, tiles_q, pp);
+      VTC_LAUNCH_CHECK();
+    }
     done = k + 1;
     if (eps >= 0.f) {
       double total = 0.0;
