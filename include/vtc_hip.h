@@ -124,16 +124,18 @@ size_t vtc_subspace_ista_fista_workspace_bytes(int64_t b, int64_t n,
                                                int64_t groups, int64_t m);
 /* grouped_dictionary (G*m, n); initial_grouped (b, G*m) or NULL;
  * grouped_codes (b, G*m) out.  Proximal step scales each group of m slots by
- * max(1 - lambda*eta/||group||_2, 0) (subspace_ista_fista.py:149-156). */
+ * max(1 - lambda*eta/||group||_2, 0) (subspace_ista_fista.py:149-156).
+ * precision: VTC_F32 (exact-f32 MFMA) or VTC_BF16X3 (bf16 hi/lo split tiles,
+ * needs n and G*m to be multiples of 4). */
 int vtc_subspace_ista_fista(const float* images,
                             const float* grouped_dictionary,
                             const float* initial_grouped, float* grouped_codes,
                             int64_t b, int64_t n, int64_t groups, int64_t m,
                             float stepsize, float sparsity_weight,
                             int num_iters, int variant,
-                            float early_stopping_epsilon, void* workspace,
-                            size_t workspace_bytes, int* iters_run,
-                            void* stream);
+                            float early_stopping_epsilon, int precision,
+                            void* workspace, size_t workspace_bytes,
+                            int* iters_run, void* stream);
 
 /* ---- convolutional inference (row a4) ---------------------------------- */
 typedef struct vtc_conv_geometry {

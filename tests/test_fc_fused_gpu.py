@@ -139,6 +139,10 @@ def test_unsupported_shapes_fall_back_or_raise(device, ista_fista):
   D = helpers.to_dev(helpers.unit_rows(2, 64, 64), device)
   with pytest.raises(NotImplementedError):
     ista_fista.run(X, D, 0.05, 5, precision='bf16', stepsize=0.3)
+  with pytest.raises(NotImplementedError):     # 6 atoms: not 16-byte rows
+    ista_fista.run(X[:, :16].contiguous(),
+                   helpers.to_dev(helpers.unit_rows(3, 6, 16), device), 0.05,
+                   5, precision='bf16x3', stepsize=0.3)
   # 'auto' silently picks the exact-f32 kernels for shapes the fused one
   # does not cover (still HIP, never CPU)
   auto = ista_fista.run(X, D, 0.05, 5, precision='auto', stepsize=0.3)
@@ -161,3 +165,33 @@ def test_lds_staged_variant_is_bit_identical(device, ista_fista, monkeypatch):
                             initial_codes=ref)
   assert torch.equal(out, ref)
   assert torch.equal(warm, warm_ref)
+
+
+@pytest.mark.parametrize('b,n,s', [(300, 64, 64), (130, 100, 200),
+                                   (64, 256, 1536)])
+def test_bf16x3_tiled_contraction_outside_the_fused_kernel(device, ista_fista,
+                                                            b, n, s):
+  """precision='bf16x3' on shapes (or with options) the fused kernel does not
+  cover runs the tiled bf16 hi/lo split contraction (gemm_x3.h)."""
+  Xn = helpers.gaussian_patches(400 + b, b, n)
+  Dn = helpers.unit_rows(401 + s, s, n)
+  eta = sc_oracle.fc_stepsize(torch.from_numpy(Dn))
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(Xn), torch.from_numpy(Dn),
+                                0.03, 30, stepsize=eta)
+  out = ista_fista.run(helpers.to_dev(Xn, device), helpers.to_dev(Dn, device),
+                       0.03, 30, precision='bf16x3', stepsize=float(eta))
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                             'tiled bf16x3 %s' % ((b, n, s),),
+                             max_flip_mag=5e-6)
+
+
+def test_bf16x3_with_early_stopping_uses_the_tiled_path(device, ista_fista):
+  g = helpers.load('fc_c1')
+  X, D = helpers.to_dev(g['images'], device), helpers.to_dev(
+      g['dictionary'], device)
+  codes = ista_fista.run(X, D, float(g['sparsity_weight']), 500,
+                         variant='fista', early_stopping_epsilon=1e-2,
+                         precision='bf16x3', stepsize=float(g['stepsize']))
+  assert 1 < ista_fista.run.last_iters < 500
+  helpers.assert_codes_match(codes.cpu().numpy(), g['codes_fista_earlystop'],
+                             1e-5, 'bf16x3 early stop', max_flip_mag=5e-6)

@@ -46,6 +46,17 @@ def test_rank_deficient_and_degenerate(device):
   diag = np.diag(np.linspace(1.0, 2.0, 256))        # clustered top end
   lam, _ = _lambda_max(diag, device)
   assert abs(lam - 2.0) < 1e-5
+  # rank 64 inside a 256 x 256 Gram (subspace test geometry: 64 atoms of 256
+  # pixels): the Krylov space is exhausted after ~64 steps
+  g = helpers.load('subspace')
+  D = g['g4_dictionary'].astype(np.float64)
+  ref = np.linalg.eigvalsh(D.T @ D)[-1]
+  lam, _ = _lambda_max(D.T @ D, device)
+  assert abs(lam - ref) / ref < 2e-6
+  D = g['ro_dictionary'].astype(np.float64)           # rank 6 in 16 x 16
+  ref = np.linalg.eigvalsh(D.T @ D)[-1]
+  lam, _ = _lambda_max(D.T @ D, device)
+  assert abs(lam - ref) / ref < 2e-6
 
 
 def test_plugin_step_size_agrees_with_library_solver(device):

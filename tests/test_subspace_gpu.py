@@ -109,3 +109,22 @@ def test_alignment_gradient_with_shared_atoms(device, plugins):
   upd.run(helpers.to_dev(Xn, device), D, helpers.to_dev(Cn, device), RAGGED,
           helpers.to_dev(hn, device), 0.05, stepsize=0.05)
   assert helpers.rel_err(D.cpu().numpy(), ref.numpy()) < helpers.REL_TOL_DICT
+
+
+def test_bf16x3_contraction_matches_reference(device, plugins):
+  """The tiled bf16 hi/lo split contraction on the subspace path."""
+  sub = plugins[0]
+  g = helpers.load('subspace')
+  X = helpers.to_dev(g['g4_images'], device)
+  D = helpers.to_dev(g['g4_dictionary'], device)
+  codes = sub.run(X, D, GROUPS4, 0.02, 40, precision='bf16x3')
+  helpers.assert_codes_match(codes.cpu().numpy(), g['g4_codes_fista'], 2e-5,
+                             'groups of 4, bf16x3', max_flip_mag=1e-5)
+  X = helpers.to_dev(helpers.gaussian_patches(24, 32, 256), device)
+  D = helpers.to_dev(helpers.unit_rows(25, 512, 256), device)
+  groups = [list(map(int, x)) for x in np.array_split(np.arange(512), 64)]
+  codes = sub.run(X, D, groups, 0.008, 50, precision='bf16x3')
+  helpers.assert_codes_match(codes.cpu().numpy(), g['c4_codes_fista'], 2e-5,
+                             'mini config 4, bf16x3', max_flip_mag=1e-5)
+  with pytest.raises(NotImplementedError):
+    sub.run(X, D, groups, 0.008, 5, precision='bf16')

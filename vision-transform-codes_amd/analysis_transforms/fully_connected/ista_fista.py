@@ -36,8 +36,11 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
       after every iteration but the first; costs a host sync per iteration).
   nonnegative_only, hard_threshold : bool, choose among the four thresholding
       functions of the reference (ista_fista.py:107-120)
-  precision : None | 'f32' | 'bf16x3' | 'bf16' -- extension, see
+  precision : None | 'auto' | 'f32' | 'bf16x3' | 'bf16' -- extension, see
       vtc_hip.set_default_precision.  None uses the process-wide default.
+      'bf16x3' runs the fused persistent kernel when the shape allows
+      (n == 256, s in {256, 512, 1024}, no early stopping) and a tiled
+      bf16 hi/lo split contraction otherwise; 'bf16' exists only fused.
   stepsize : float, optional -- extension: skip the Lipschitz eigen-solve and
       use this eta (tests inject the eta of a golden vector this way).
 

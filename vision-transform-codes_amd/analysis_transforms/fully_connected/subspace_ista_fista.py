@@ -18,13 +18,16 @@ from vtc_hip import groups as group_tables
 def run(images, dictionary, group_assignments, sparsity_weight,
         num_iters, variant='fista', ret_summed_gduplicates=True,
         initial_codes=None, early_stopping_epsilon=None, hard_threshold=False,
-        stepsize=None):
+        stepsize=None, precision=None):
   """
   images (b, n), dictionary (s, n): float32 tensors on a HIP device.
   group_assignments : list of index lists, e.g. [[0, 2, 5], [1], [2, 3, 4, 5]]
   Returns codes (b, s); an atom that belongs to several groups gets the sum of
   its per-group coefficients (ret_summed_gduplicates=True, the only mode the
-  reference implements).  `stepsize` is an extension (skip the eigen-solve).
+  reference implements).  Extensions: `stepsize` (skip the eigen-solve) and
+  `precision` in {None, 'auto', 'f32', 'bf16x3'}: 'auto' (the default policy)
+  uses the bf16 hi/lo split contraction for large problems (>= 1024 slots)
+  and the exact-f32 one otherwise.
   """
   assert variant in ['ista', 'fista']
   if hard_threshold:
@@ -74,12 +77,20 @@ def run(images, dictionary, group_assignments, sparsity_weight,
   iters_run = ctypes.c_int(0)
   eps = -1.0 if early_stopping_epsilon is None else float(
       early_stopping_epsilon)
+  name = precision if precision is not None else (
+      vtc_hip.get_default_precision())
+  if name == 'auto':
+    name = 'bf16x3' if (slots >= 1024 and slots % 4 == 0 and n % 4 == 0) else (
+        'f32')
+  if name == 'bf16':
+    raise NotImplementedError('subspace inference has no bf16 fast mode')
   vtc_hip.check(lib.vtc_subspace_ista_fista(
       vtc_hip.ptr(images), vtc_hip.ptr(grouped_dictionary),
       vtc_hip.ptr(initial_grouped), vtc_hip.ptr(grouped_codes), b, n,
       num_groups, m, float(stepsize), float(sparsity_weight), int(num_iters),
-      vtc_hip.variant_code(variant), eps, vtc_hip.ptr(ws), ws.numel(),
-      ctypes.byref(iters_run), stream), 'vtc_subspace_ista_fista')
+      vtc_hip.variant_code(variant), eps, vtc_hip.PRECISIONS[name],
+      vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run), stream),
+      'vtc_subspace_ista_fista')
   run.last_iters = iters_run.value
 
   codes = torch.empty((b, s), dtype=torch.float32, device=device)

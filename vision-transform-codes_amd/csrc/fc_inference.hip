@@ -12,6 +12,7 @@
 // stay at f32 summation-order level.
 #include "common.h"
 #include "gemm_f32.h"
+#include "gemm_x3.h"
 #include "fc_fused.h"
 
 #include <math.h>
@@ -67,20 +68,25 @@ struct GenericLayout {
   size_t y_elems, r_elems;
 };
 
+int launch_transpose(const float* in, float* out, int64_t rows, int64_t cols,
+                     hipStream_t st);  // subspace.hip
+
 static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
   size_t bytes = 0;
   bytes += align_up((size_t)b * s * sizeof(float), 256);  // Y
   bytes += align_up((size_t)b * n * sizeof(float), 256);  // R
+  bytes += align_up((size_t)s * n * sizeof(float), 256);  // D^T (bf16x3)
   bytes += 256;                                           // stop accumulator
   return bytes;
 }
 
-static int run_generic_f32(const float* images, const float* dictionary,
-                           const float* initial_codes, float* codes, int64_t b,
-                           int64_t n, int64_t s, float eta, float cutoff,
-                           int num_iters, int variant, int threshold,
-                           float eps, void* workspace, size_t workspace_bytes,
-                           int* iters_run, hipStream_t st) {
+// x3 = false: exact-f32 MFMA; x3 = true: bf16 hi/lo split tiles (gemm_x3.h)
+static int run_generic(const float* images, const float* dictionary,
+                       const float* initial_codes, float* codes, int64_t b,
+                       int64_t n, int64_t s, float eta, float cutoff,
+                       int num_iters, int variant, int threshold, float eps,
+                       bool x3, void* workspace, size_t workspace_bytes,
+                       int* iters_run, hipStream_t st) {
   if (workspace_bytes < generic_workspace_bytes(b, n, s) || !workspace) {
     set_error("vtc_fc_ista_fista: workspace too small (%zu < %zu)",
               workspace_bytes, generic_workspace_bytes(b, n, s));
@@ -89,10 +95,20 @@ static int run_generic_f32(const float* images, const float* dictionary,
   Carver ws(workspace);
   float* Ybuf = ws.take<float>((size_t)b * s);
   float* R = ws.take<float>((size_t)b * n);
+  float* Dt = ws.take<float>((size_t)s * n);
   double* delta_sum = ws.take<double>(1);
 
   const bool fista = (variant == VTC_FISTA);
   float* Y = fista ? Ybuf : codes;  // ISTA evaluates the gradient at the codes
+  if (x3) {
+    if (!gemm_x3_usable(Y, s, Dt, s) || !gemm_x3_usable(R, n, dictionary, n)) {
+      set_error("vtc_fc_ista_fista: bf16x3 outside the fused kernel needs n "
+                "and s to be multiples of 4 and 16-byte aligned operands");
+      return VTC_ERR_UNSUPPORTED;
+    }
+    int rc = launch_transpose(dictionary, Dt, s, n, st);
+    if (rc != VTC_OK) return rc;
+  }
   const size_t code_bytes = (size_t)b * s * sizeof(float);
   if (initial_codes) {
     VTC_HIP_CHECK(hipMemcpyAsync(codes, initial_codes, code_bytes,
@@ -111,15 +127,18 @@ static int run_generic_f32(const float* images, const float* dictionary,
   for (int k = 0; k < num_iters; ++k) {
     // R = Y D - X : A = Y (b,s) k-contiguous, B = D (s,n) = [K][N]
     EpiMinus e1{R, images, n, n};
-    int rc = launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1, e1,
-                                          st);
+    int rc = x3 ? launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st)
+                : launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1,
+                                               e1, st);
     if (rc != VTC_OK) return rc;
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     // G = R D^T : A = R (b,n) k-contiguous, B = D (s,n) = [N][K]
     EpiProx e2{Y, codes, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
                fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0};
-    rc = launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1, e2, st);
+    rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st)
+            : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1, e2,
+                                          st);
     if (rc != VTC_OK) return rc;
     done = k + 1;
     if (eps >= 0.f) {
@@ -143,8 +162,13 @@ extern "C" size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n,
                                                     int64_t s,
                                                     int precision) {
   if (b <= 0 || n <= 0 || s <= 0) return 256;
-  if (precision == VTC_F32) return generic_workspace_bytes(b, n, s);
-  return fused_workspace_bytes(b, n, s, precision);
+  const size_t generic = generic_workspace_bytes(b, n, s);
+  if (precision == VTC_F32) return generic;
+  const size_t fused = fused_workspace_bytes(b, n, s, precision);
+  // bf16x3 falls back to the tiled bf16x3 contraction for shapes (or options)
+  // the fused kernel does not cover: size for the larger of the two
+  if (precision == VTC_BF16X3) return fused > generic ? fused : generic;
+  return fused;
 }
 
 extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
@@ -172,19 +196,20 @@ extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
   // lambda*eta: the Python float is rounded to f32, then one f32 multiply
   const float cutoff = sparsity_weight * stepsize;
   hipStream_t st = as_stream(stream);
-  if (precision != VTC_F32) {
-    if (early_stopping_epsilon >= 0.f ||
-        !fused_shape_supported(b, n, s, precision)) {
-      set_error("vtc_fc_ista_fista: precision %d supports only n == 256, "
-                "s %% 128 == 0 and no early stopping; use VTC_F32", precision);
-      return VTC_ERR_UNSUPPORTED;
-    }
+  const bool fused_ok = early_stopping_epsilon < 0.f &&
+                        fused_shape_supported(b, n, s, precision);
+  if (precision == VTC_BF16 && !fused_ok) {
+    set_error("vtc_fc_ista_fista: VTC_BF16 exists only as the fused kernel "
+              "(n == 256, s in {256, 512, 1024}, no early stopping); use "
+              "VTC_BF16X3 or VTC_F32");
+    return VTC_ERR_UNSUPPORTED;
+  }
+  if (precision != VTC_F32 && fused_ok)
     return run_fused(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, cutoff, num_iters, variant, threshold,
                      precision, workspace, workspace_bytes, iters_run, st);
-  }
-  return run_generic_f32(images, dictionary, initial_codes, codes, b, n, s,
-                         stepsize, cutoff, num_iters, variant, threshold,
-                         early_stopping_epsilon, workspace, workspace_bytes,
-                         iters_run, st);
+  return run_generic(images, dictionary, initial_codes, codes, b, n, s,
+                     stepsize, cutoff, num_iters, variant, threshold,
+                     early_stopping_epsilon, precision == VTC_BF16X3,
+                     workspace, workspace_bytes, iters_run, st);
 }

@@ -1,0 +1,205 @@
+// Tiled contraction with float32-level accuracy on the bf16 matrix pipe
+// ("bf16x3"), for shapes the fused FISTA kernel does not cover.
+//
+//   C[M,N] = A[M,K] * B[N,K]^T         A, B float32 in HBM, k contiguous
+//
+// While a tile is staged into LDS every f32 value is split into
+//   hi = bf16(x),  lo = bf16(x - float(hi))
+// and the product is formed as hi*hi + hi*lo + lo*hi with
+// v_mfma_f32_32x32x16_bf16, f32 accumulate: relative error ~2^-16 per product
+// (measured end to end: same as the reference's own f32 noise after 200 FISTA
+// iterations) at 3 MFMA per algorithmic product, i.e. 5.3x the peak of the
+// exact-f32 MFMA used by gemm_f32.h.
+//
+// Block = 4 waves (2x2), block tile 128x128, wave tile 64x64 (2x2 MFMA tiles),
+// K step 32.  LDS rows are 64 B (32 bf16); the 16-byte chunk index is XORed
+// with (row >> 2) & 3 so that the 16 lanes of a ds_read_b128 group (16 rows,
+// same chunk) hit 16 different 16-byte slots.
+#pragma once
+
+#include "common.h"
+#include "gemm_f32.h"
+
+namespace vtc {
+
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kX3BM = 128, kX3BN = 128, kX3BK = 32;
+constexpr int kX3TileBytes = 128 * 64;   // one operand part: 128 rows x 64 B
+
+struct GemmX3Args {
+  const float* A;
+  const float* B;
+  int64_t M, N, K;
+  int64_t lda, ldb;
+};
+
+__device__ __forceinline__ int x3_lds_off(int row, int chunk) {
+  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
+
+// global (f32) -> registers: 128 rows x 32 k, thread handles 4 float4
+__device__ __forceinline__ void x3_stage_load(const float* P, int64_t ld,
+                                              int64_t line0, int64_t lines,
+                                              int64_t k0, int64_t K, int tid,
+                                              float4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + i * 256;
+    const int line = f >> 3, kq = f & 7;
+    const int64_t gl = line0 + line, gk = k0 + kq * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gl < lines && gk < K) {
+      const float* src = P + gl * ld + gk;
+      if (gk + 3 < K) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        v.x = src[0];
+        if (gk + 1 < K) v.y = src[1];
+        if (gk + 2 < K) v.z = src[2];
+      }
+    }
+    regs[i] = v;
+  }
+}
+
+// registers -> LDS as bf16 hi / lo parts
+__device__ __forceinline__ void x3_stage_store(char* hi_base, char* lo_base,
+                                               int tid,
+                                               const float4 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = tid + i * 256;
+    const int line = f >> 3, kq = f & 7;
+    const float v[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+    x3_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    const int off = x3_lds_off(line, kq >> 1) + 8 * (kq & 1);
+    *reinterpret_cast<uint2*>(hi_base + off) = __builtin_bit_cast(uint2, hi);
+    *reinterpret_cast<uint2*>(lo_base + off) = __builtin_bit_cast(uint2, lo);
+  }
+}
+
+template <class Epi>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
+  // [buf][A_hi, A_lo, B_hi, B_lo][128 rows][64 B]
+  __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int64_t tiles_n = (g.N + kX3BN - 1) / kX3BN;
+  const int64_t m0 = ((int64_t)blockIdx.x / tiles_n) * kX3BM;
+  const int64_t n0 = ((int64_t)blockIdx.x % tiles_n) * kX3BN;
+  const int nk = (int)((g.K + kX3BK - 1) / kX3BK);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], rb[4];
+  x3_stage_load(g.A, g.lda, m0, g.M, 0, g.K, tid, ra);
+  x3_stage_load(g.B, g.ldb, n0, g.N, 0, g.K, tid, rb);
+  x3_stage_store(lds[0][0], lds[0][1], tid, ra);
+  x3_stage_store(lds[0][2], lds[0][3], tid, rb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      const int64_t k0 = (int64_t)(kt + 1) * kX3BK;
+      x3_stage_load(g.A, g.lda, m0, g.M, k0, g.K, tid, ra);
+      x3_stage_load(g.B, g.ldb, n0, g.N, k0, g.K, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = 2 * kk + half;
+      uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int arow = wm * 64 + t * 32 + l31;
+        const int brow = wn * 64 + t * 32 + l31;
+        ah[t] = *reinterpret_cast<const uint4*>(lds[cur][0] +
+                                                x3_lds_off(arow, chunk));
+        al[t] = *reinterpret_cast<const uint4*>(lds[cur][1] +
+                                                x3_lds_off(arow, chunk));
+        bh[t] = *reinterpret_cast<const uint4*>(lds[cur][2] +
+                                                x3_lds_off(brow, chunk));
+        bl[t] = *reinterpret_cast<const uint4*>(lds[cur][3] +
+                                                x3_lds_off(brow, chunk));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(x3_bf16x8, ah[mi]),
+              __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(x3_bf16x8, ah[mi]),
+              __builtin_bit_cast(x3_bf16x8, bl[ni]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(x3_bf16x8, al[mi]),
+              __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      x3_stage_store(lds[cur ^ 1][0], lds[cur ^ 1][1], tid, ra);
+      x3_stage_store(lds[cur ^ 1][2], lds[cur ^ 1][3], tid, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int64_t col = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row =
+            m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], 0);
+      }
+    }
+  }
+  epi.block_end();
+}
+
+// Usable when both operands allow aligned 16-byte loads along k.
+static inline bool gemm_x3_usable(const float* A, int64_t lda, const float* B,
+                                  int64_t ldb) {
+  return gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb);
+}
+
+template <class Epi>
+static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
+                          int64_t ldb, int64_t M, int64_t N, int64_t K,
+                          Epi epi, hipStream_t st) {
+  if (M <= 0 || N <= 0) return VTC_OK;
+  GemmX3Args g{A, B, M, N, K, lda, ldb};
+  const int64_t tiles = ceil_div(M, kX3BM) * ceil_div(N, kX3BN);
+  if (tiles > 0x7fffffffLL) {
+    set_error("gemm_x3: too many tiles");
+    return VTC_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL((gemm_x3_kernel<Epi>), dim3((unsigned)tiles), dim3(256),
+                     0, st, g, epi);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+}  // namespace vtc

@@ -32,6 +32,35 @@ __device__ __forceinline__ double block_sum_vec(double v, double* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Largest eigenvalue of the symmetric tridiagonal matrix (alpha, beta) of
+// order m by bisection on Sturm counts, double precision, one lane.
+__device__ double tridiagonal_lambda_max(const double* alpha,
+                                         const double* beta, int m) {
+  double lo = alpha[0], hi = alpha[0];
+  for (int i = 0; i < m; ++i) {
+    const double off = (i > 0 ? fabs(beta[i - 1]) : 0.0) +
+                       (i + 1 < m ? fabs(beta[i]) : 0.0);
+    lo = fmin(lo, alpha[i] - off);
+    hi = fmax(hi, alpha[i] + off);
+  }
+  if (!(hi == hi) || !(lo == lo)) return hi + lo;  // NaN propagates
+  // smallest x with (#eigenvalues < x) == m
+  for (int it = 0; it < 200 && hi - lo > 1e-14 * fmax(fabs(hi), fabs(lo));
+       ++it) {
+    const double x = 0.5 * (lo + hi);
+    int below = 0;
+    double d = 1.0;
+    for (int i = 0; i < m; ++i) {
+      const double off2 = (i > 0) ? beta[i - 1] * beta[i - 1] : 0.0;
+      d = (alpha[i] - x) - (i > 0 ? off2 / d : 0.0);
+      if (d == 0.0) d = -1e-300;
+      if (d < 0.0) ++below;
+    }
+    if (below == m) hi = x; else lo = x;
+  }
+  return 0.5 * (lo + hi);
+}
+
 // Thread layout: tid = part * 256 + t.  Component t of every vector belongs
 // to the threads (.., t); part 0 owns the Lanczos recurrences, parts 1..3 only
 // help with the mat-vec and the Gram-Schmidt sums.
@@ -46,6 +75,8 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
   __shared__ double alpha[kLanczosMaxK];
   __shared__ double beta[kLanczosMaxK];
   __shared__ int steps_done;
+  __shared__ int stop_flag;
+  __shared__ double last_ritz;
   const int tid = threadIdx.x;
   const int t = tid & 255, part = tid >> 8;
   const int lane = tid & 63, wave = tid >> 6;   // 16 waves
@@ -63,7 +94,12 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
   v = (float)(v / nrm);
   float v_prev = 0.f;
   double beta_prev = 0.0;
-  if (tid == 0) steps_done = k;
+  if (tid == 0) {
+    steps_done = k;
+    stop_flag = 0;
+    last_ritz = -1.0;
+  }
+  double tscale = 0.0;
   const int rows_per_part = (n + kLanczosParts - 1) / kLanczosParts;
   const int i0 = part * rows_per_part;
   const int i1 = (i0 + rows_per_part < n) ? i0 + rows_per_part : n;
@@ -123,11 +159,29 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
       alpha[j] = a;
       beta[j] = b;
     }
-    // invariant subspace reached (or a NaN): the tridiagonal matrix so far
-    // already holds the spectrum of the reachable space
-    if (!(b > 1e-7 * fabs(a) + 1e-30)) {
+    tscale = fmax(tscale, fmax(fabs(a), b));
+    // Krylov space exhausted (rank-deficient Gram, invariant subspace) or a
+    // NaN: what is left of w is rounding noise -- normalising it would feed
+    // amplified garbage into the recurrence.  The tridiagonal matrix so far
+    // already holds the spectrum of the reachable space.
+    if (!(b > 1e-5 * tscale)) {
       if (tid == 0) steps_done = j + 1;
       break;
+    }
+    // every 8 steps: has the top Ritz value stopped moving?  (it grows
+    // monotonically with the Krylov dimension)
+    if ((j & 7) == 7) {
+      if (tid == 0) {
+        const double ritz = tridiagonal_lambda_max(alpha, beta, j + 1);
+        stop_flag = (last_ritz > 0.0 &&
+                     fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
+        last_ritz = ritz;
+      }
+      __syncthreads();
+      if (stop_flag) {
+        if (tid == 0) steps_done = j + 1;
+        break;
+      }
     }
     v_prev = v;
     v = (float)(w / b);
@@ -136,35 +190,7 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
   __syncthreads();
 
   if (tid == 0) {
-    const int m = steps_done;
-    // Gershgorin bounds of the tridiagonal matrix
-    double lo = alpha[0], hi = alpha[0];
-    for (int i = 0; i < m; ++i) {
-      const double off = (i > 0 ? fabs(beta[i - 1]) : 0.0) +
-                         (i + 1 < m ? fabs(beta[i]) : 0.0);
-      lo = fmin(lo, alpha[i] - off);
-      hi = fmax(hi, alpha[i] + off);
-    }
-    double lambda;
-    if (!(hi == hi) || !(lo == lo)) {
-      lambda = hi + lo;  // NaN propagates to the caller
-    } else {
-      // largest eigenvalue: smallest x with (#eigenvalues < x) == m
-      for (int it = 0; it < 200 && hi - lo > 1e-14 * fmax(fabs(hi), fabs(lo));
-           ++it) {
-        const double x = 0.5 * (lo + hi);
-        int below = 0;
-        double d = 1.0;
-        for (int i = 0; i < m; ++i) {
-          const double off2 = (i > 0) ? beta[i - 1] * beta[i - 1] : 0.0;
-          d = (alpha[i] - x) - (i > 0 ? off2 / d : 0.0);
-          if (d == 0.0) d = -1e-300;
-          if (d < 0.0) ++below;
-        }
-        if (below == m) hi = x; else lo = x;
-      }
-      lambda = 0.5 * (lo + hi);
-    }
+    const double lambda = tridiagonal_lambda_max(alpha, beta, steps_done);
     const float lf = (float)lambda;
     out[0] = lf;
     out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32

@@ -12,6 +12,7 @@
 //                                                (patch, group)
 #include "common.h"
 #include "gemm_f32.h"
+#include "gemm_x3.h"
 #include "fc_fused.h"
 
 #include <vector>
@@ -106,8 +107,37 @@ __global__ __launch_bounds__(256) void group_prox_kernel(
 }
 
 static size_t subspace_ws_bytes(int64_t b, int64_t n, int64_t slots) {
-  return align_up((size_t)b * slots * sizeof(float), 256) +
-         align_up((size_t)b * n * sizeof(float), 256) + 256;
+  return align_up((size_t)b * slots * sizeof(float), 256) +   // Y
+         align_up((size_t)b * n * sizeof(float), 256) +       // R
+         align_up((size_t)slots * n * sizeof(float), 256) +   // Dg^T (bf16x3)
+         256;
+}
+
+// out[c][r] = in[r][c]
+__global__ void transpose_kernel(const float* __restrict__ in,
+                                 float* __restrict__ out, int64_t rows,
+                                 int64_t cols) {
+  __shared__ float tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < rows && c < cols) ? in[r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int64_t c = c0 + i, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) out[c * rows + r] = tile[threadIdx.x][i];
+  }
+}
+
+int launch_transpose(const float* in, float* out, int64_t rows, int64_t cols,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel,
+                     dim3((unsigned)ceil_div(cols, 32),
+                          (unsigned)ceil_div(rows, 32)),
+                     dim3(32, 8), 0, st, in, out, rows, cols);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
 }
 
 static unsigned flat_grid(int64_t total) {
@@ -178,10 +208,13 @@ extern "C" int vtc_subspace_ista_fista(
     const float* images, const float* grouped_dictionary,
     const float* initial_grouped, float* grouped_codes, int64_t b, int64_t n,
     int64_t groups, int64_t m, float stepsize, float sparsity_weight,
-    int num_iters, int variant, float early_stopping_epsilon, void* workspace,
-    size_t workspace_bytes, int* iters_run, void* stream) {
+    int num_iters, int variant, float early_stopping_epsilon, int precision,
+    void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
   VTC_REQUIRE(images && grouped_dictionary && grouped_codes,
               "vtc_subspace_ista_fista: null pointer");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
+              "vtc_subspace_ista_fista: precision must be VTC_F32 or "
+              "VTC_BF16X3");
   VTC_REQUIRE(b >= 0 && n > 0 && groups > 0 && m > 0,
               "vtc_subspace_ista_fista: bad sizes");
   VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
@@ -198,10 +231,24 @@ extern "C" int vtc_subspace_ista_fista(
   Carver ws(workspace);
   float* Y = ws.take<float>((size_t)b * slots);
   float* R = ws.take<float>((size_t)b * n);
+  float* DgT = ws.take<float>((size_t)slots * n);
   double* delta_sum = ws.take<double>(1);
   const float eta = stepsize;
   const float cutoff = sparsity_weight * stepsize;
   const float eps = early_stopping_epsilon;
+  // bf16x3 contractions need both operands k-contiguous: Y (b,slots) with
+  // Dg^T (n,slots) for the residual, R (b,n) with Dg (slots,n) for the gradient
+  const bool x3 = (precision == VTC_BF16X3);
+  if (x3) {
+    if (!gemm_x3_usable(Y, slots, DgT, slots) ||
+        !gemm_x3_usable(R, n, grouped_dictionary, n)) {
+      set_error("vtc_subspace_ista_fista: bf16x3 needs n and G*m to be "
+                "multiples of 4 and 16-byte aligned operands");
+      return VTC_ERR_UNSUPPORTED;
+    }
+    int rc = launch_transpose(grouped_dictionary, DgT, slots, n, st);
+    if (rc != VTC_OK) return rc;
+  }
   const bool fista = (variant == VTC_FISTA);
   const size_t bytes = (size_t)b * slots * sizeof(float);
   if (initial_grouped) {
@@ -218,12 +265,14 @@ extern "C" int vtc_subspace_ista_fista(
   int done = 0;
   for (int k = 0; k < num_iters; ++k) {
     EpiMinus e1{R, images, n, n};
-    int rc = launch_gemm_f32<true, false>(Y, slots, grouped_dictionary, n, b,
-                                          n, slots, 1, e1, st);
+    int rc = x3 ? launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, e1, st)
+                : launch_gemm_f32<true, false>(Y, slots, grouped_dictionary, n,
+                                               b, n, slots, 1, e1, st);
     if (rc != VTC_OK) return rc;
     EpiGradStep e2{Y, slots, eta};
-    rc = launch_gemm_f32<true, true>(R, n, grouped_dictionary, n, b, slots, n,
-                                     1, e2, st);
+    rc = x3 ? launch_gemm_x3(R, n, grouped_dictionary, n, b, slots, n, e2, st)
+            : launch_gemm_f32<true, true>(R, n, grouped_dictionary, n, b,
+                                          slots, n, 1, e2, st);
     if (rc != VTC_OK) return rc;
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));

@@ -67,7 +67,8 @@ SIGNATURES = {
     'vtc_subspace_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i64]),
     'vtc_subspace_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _f32, _f32, _i32, _i32, _f32,
-                                       _vp, _sz, ctypes.POINTER(_i32), _vp]),
+                                       _i32, _vp, _sz, ctypes.POINTER(_i32),
+                                       _vp]),
     'vtc_conv_code_dims': (_i32, [_GEOM_P, ctypes.POINTER(ctypes.c_int32),
                                   ctypes.POINTER(ctypes.c_int32)]),
     'vtc_conv_ista_fista_workspace_bytes': (_sz, [_GEOM_P]),
