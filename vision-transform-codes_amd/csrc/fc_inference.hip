@@ -64,10 +64,6 @@ void fista_betas(int num_iters, std::vector<float>* out) {
   }
 }
 
-struct GenericLayout {
-  size_t y_elems, r_elems;
-};
-
 int launch_transpose(const float* in, float* out, int64_t rows, int64_t cols,
                      hipStream_t st);  // subspace.hip
 
