@@ -484,8 +484,14 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
         G = VTC_MFMA(ring[0][i % RING], rb[1], G);
         G = VTC_MFMA(ring[1][i % RING], rb[0], G);
       }
+      // epilogue arithmetic first, then the refill: a wave blocks at a
+      // buffer load while the vector-memory path is busy, and in that order
+      // its VALU work would wait behind the load instead of overlapping it
+      if (overlap) {
+        epilogue_elem(p - 1, i, Gb[(p - 1) & 1], beta);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       VTC_REFILL(sg, i)
-      if (overlap) epilogue_elem(p - 1, i, Gb[(p - 1) & 1], beta);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
