@@ -195,3 +195,29 @@ def test_bf16x3_with_early_stopping_uses_the_tiled_path(device, ista_fista):
   assert 1 < ista_fista.run.last_iters < 500
   helpers.assert_codes_match(codes.cpu().numpy(), g['codes_fista_earlystop'],
                              1e-5, 'bf16x3 early stop', max_flip_mag=5e-6)
+
+
+def test_private_transposition_variant(device, ista_fista, monkeypatch):
+  """VTC_FUSED_VARIANT=3: each wave keeps the residual update to its own atoms
+  and transposes its dictionary fragments through a private LDS scratch.  The
+  residual is summed in a different order than in the default variant, so the
+  comparison is with the reference at bf16 tolerances."""
+  g, X, D, lam, eta = _c2(device)
+  monkeypatch.setenv('VTC_FUSED_VARIANT', '3')
+  for k, tol in ((1, 2e-2), (2, 2e-2), (20, 2e-2), (200, REL_TOL_BF16)):
+    out = ista_fista.run(X, D, lam, k, precision='bf16', stepsize=eta)
+    err = helpers.rel_err(out.cpu().numpy(), g['codes_fista_T%d' % k])
+    print('variant 3 bf16 T=%d rel %.2e' % (k, err))
+    assert err < tol
+  again = ista_fista.run(X, D, lam, 200, precision='bf16', stepsize=eta)
+  assert torch.equal(out, again)                   # reproducible
+  init = helpers.to_dev(g['codes_fista_T20'], device)
+  warm = ista_fista.run(X, D, lam, 20, precision='bf16', stepsize=eta,
+                        initial_codes=init)
+  assert helpers.rel_err(warm.cpu().numpy(), g['codes_fista_warm20']) < 2e-2
+  Xr = helpers.to_dev(helpers.gaussian_patches(7, 45, 256), device)  # ragged b
+  Dn = helpers.to_dev(helpers.unit_rows(8, 256, 256), device)
+  part = ista_fista.run(Xr, Dn, 0.02, 30, precision='bf16', stepsize=0.3)
+  monkeypatch.delenv('VTC_FUSED_VARIANT')
+  ref = ista_fista.run(Xr, Dn, 0.02, 30, precision='bf16x3', stepsize=0.3)
+  assert helpers.rel_err(part.cpu().numpy(), ref.cpu().numpy()) < 2e-2

@@ -851,6 +851,10 @@ __global__ __launch_bounds__(256, 1) void fused_fista_lds_kernel(
   }
 }
 
+}  // namespace vtc
+#include "fc_fused_priv.h"
+namespace vtc {
+
 // -------------------------------------------------------------------- host
 static int phases_for(int64_t s) { return (int)(s / kPhaseAtoms); }
 
@@ -999,6 +1003,62 @@ static int dispatch_lds(const FusedParams& P, int threshold, hipStream_t st) {
   return VTC_ERR_UNSUPPORTED;
 }
 
+// ---- variant 3 (private transposition, bf16) ------------------------------
+template <int NPH, int MODE, bool STAMP>
+static int launch_priv(FusedParams P, hipStream_t st) {
+  auto kernel = fused_fista_priv_kernel<NPH, MODE, STAMP>;
+  static bool configured = false;
+  if (!configured) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, PrivLds<NPH>::total));
+    configured = true;
+  }
+  unsigned long long* dev = nullptr;
+  if (STAMP) {
+    VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
+    VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
+    P.stamps = dev;
+  }
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
+                     PrivLds<NPH>::total, st, P);
+  VTC_LAUNCH_CHECK();
+  if (STAMP) {
+    unsigned long long host[8];
+    VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host),
+                                 hipMemcpyDeviceToHost, st));
+    VTC_HIP_CHECK(hipStreamSynchronize(st));
+    VTC_HIP_CHECK(hipFree(dev));
+    const char* names[5] = {"step1", "epilogue", "-", "step3", "reduce-R"};
+    print_stamps(host, P.num_iters, NPH, names);
+  }
+  return VTC_OK;
+}
+
+template <int NPH>
+static int dispatch_priv_mode(const FusedParams& P, int threshold,
+                              hipStream_t st) {
+  if (threshold == VTC_SOFT && getenv("VTC_FUSED_STAMPS"))
+    return launch_priv<NPH, VTC_SOFT, true>(P, st);
+  switch (threshold) {
+    case VTC_SOFT: return launch_priv<NPH, VTC_SOFT, false>(P, st);
+    case VTC_SOFT_NONNEG:
+      return launch_priv<NPH, VTC_SOFT_NONNEG, false>(P, st);
+    case VTC_HARD: return launch_priv<NPH, VTC_HARD, false>(P, st);
+    default: return launch_priv<NPH, VTC_HARD_NONNEG, false>(P, st);
+  }
+}
+
+static int dispatch_priv(const FusedParams& P, int threshold, hipStream_t st) {
+  switch (phases_for(P.s)) {
+    case 2: return dispatch_priv_mode<2>(P, threshold, st);
+    case 4: return dispatch_priv_mode<4>(P, threshold, st);
+    case 8: return dispatch_priv_mode<8>(P, threshold, st);
+  }
+  set_error("fused FISTA: unsupported atom count %d", P.s);
+  return VTC_ERR_UNSUPPORTED;
+}
+
 template <int NP>
 static int dispatch_phases(const FusedParams& P, int threshold,
                            hipStream_t st) {
@@ -1082,9 +1142,12 @@ int run_fused(const float* images, const float* dictionary,
   P.eta = eta;
   P.cutoff = cutoff;
   P.stamps = nullptr;
-  int rc = use_lds_variant ? dispatch_lds(P, threshold, st)
-           : (parts == 2)  ? dispatch_phases<2>(P, threshold, st)
-                           : dispatch_phases<1>(P, threshold, st);
+  const bool use_priv_variant =
+      (parts == 1) && variant_env && variant_env[0] == '3';
+  int rc = use_lds_variant    ? dispatch_lds(P, threshold, st)
+           : use_priv_variant ? dispatch_priv(P, threshold, st)
+           : (parts == 2)     ? dispatch_phases<2>(P, threshold, st)
+                              : dispatch_phases<1>(P, threshold, st);
   if (rc == VTC_OK && iters_run) *iters_run = num_iters;
   return rc;
 }
