@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   using L = FusedLds<NPH, NP>;
   constexpr int CREG = L::CREG;
   constexpr int CR = CREG > 0 ? CREG : 1;
-  constexpr int RING = (NP == 1) ? 16 : 8;  // fragments (k-steps) in flight
+  // fragments (k-steps) in flight; must divide 16.  bf16x3 with 16 spills and
+  // measures slower (77.7 vs 74.8 ms): the phases are bandwidth-, not
+  // latency-bound
+  constexpr int RING = (NP == 1) ? 16 : 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Cst = smem;
   char* Yx = smem + L::cst_bytes;
