@@ -128,3 +128,25 @@ def test_bf16x3_contraction_matches_reference(device, plugins):
                              'mini config 4, bf16x3', max_flip_mag=1e-5)
   with pytest.raises(NotImplementedError):
     sub.run(X, D, groups, 0.008, 5, precision='bf16')
+
+
+@pytest.mark.parametrize('m,precision', [(3, 'f32'), (5, 'f32'), (2, 'f32'),
+                                         (1, 'f32'), (16, 'bf16x3')])
+def test_group_sizes_against_oracle(device, plugins, m, precision):
+  """Power-of-two group sizes take the coalesced shuffle kernel, the others
+  the thread-per-group kernel; both against the oracle."""
+  sub = plugins[0]
+  num_groups = 12
+  s_atoms, n = num_groups * m, 64
+  if precision == 'bf16x3':
+    s_atoms, n = 16 * 16, 64
+    num_groups = 16
+  groups = [list(range(g * m, g * m + m)) for g in range(num_groups)]
+  Xn = helpers.gaussian_patches(500 + m, 40, n)
+  Dn = helpers.unit_rows(501 + m, s_atoms, n)
+  ref = sc_oracle.subspace_ista_fista(torch.from_numpy(Xn),
+                                      torch.from_numpy(Dn), groups, 0.03, 25)
+  out = sub.run(helpers.to_dev(Xn, device), helpers.to_dev(Dn, device), groups,
+                0.03, 25, precision=precision)
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                             'groups of %d' % m, max_flip_mag=1e-5)

@@ -31,6 +31,30 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int slices,
   }
 }
 
+__global__ void slab_reduce_minus_kernel(const float* __restrict__ slabs,
+                                         int slices, int64_t count,
+                                         const float* __restrict__ X,
+                                         float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride) {
+    float acc = slabs[i];
+    for (int z = 1; z < slices; ++z) acc += slabs[(int64_t)z * count + i];
+    out[i] = sub_rn(acc, X[i]);
+  }
+}
+
+int launch_slab_reduce_minus(const float* slabs, int slices, int64_t count,
+                             const float* X, float* out, hipStream_t st) {
+  if (count <= 0) return VTC_OK;
+  int64_t blocks = ceil_div(count, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(slab_reduce_minus_kernel, dim3((unsigned)blocks),
+                     dim3(256), 0, st, slabs, slices, count, X, out);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
 int launch_slab_reduce(const float* slabs, int slices, int64_t count,
                        float* out, hipStream_t st) {
   if (count <= 0) return VTC_OK;

@@ -72,6 +72,8 @@ static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
   bytes += align_up((size_t)b * s * sizeof(float), 256);  // Y
   bytes += align_up((size_t)b * n * sizeof(float), 256);  // R
   bytes += align_up((size_t)s * n * sizeof(float), 256);  // D^T (bf16x3)
+  bytes += align_up((size_t)gemm_x3_want_slices(b, n, s) * b * n *
+                        sizeof(float), 256);  // split-K slabs
   bytes += 256;                                           // stop accumulator
   return bytes;
 }
@@ -92,6 +94,8 @@ static int run_generic(const float* images, const float* dictionary,
   float* Ybuf = ws.take<float>((size_t)b * s);
   float* R = ws.take<float>((size_t)b * n);
   float* Dt = ws.take<float>((size_t)s * n);
+  const int k1_slices = x3 ? gemm_x3_want_slices(b, n, s) : 1;
+  float* slabs = ws.take<float>((size_t)gemm_x3_want_slices(b, n, s) * b * n);
   double* delta_sum = ws.take<double>(1);
 
   const bool fista = (variant == VTC_FISTA);
@@ -123,9 +127,18 @@ static int run_generic(const float* images, const float* dictionary,
   for (int k = 0; k < num_iters; ++k) {
     // R = Y D - X : A = Y (b,s) k-contiguous, B = D (s,n) = [K][N]
     EpiMinus e1{R, images, n, n};
-    int rc = x3 ? launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st)
-                : launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1,
-                                               e1, st);
+    int rc;
+    if (x3 && k1_slices > 1) {
+      EpiSlab es{slabs, b * n, n};
+      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, es, st, k1_slices);
+      if (rc == VTC_OK)
+        rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st);
+    } else if (x3) {
+      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st);
+    } else {
+      rc = launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1, e1,
+                                        st);
+    }
     if (rc != VTC_OK) return rc;
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));

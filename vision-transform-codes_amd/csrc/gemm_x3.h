@@ -33,6 +33,7 @@ struct GemmX3Args {
   const float* B;
   int64_t M, N, K;
   int64_t lda, ldb;
+  int64_t k_chunk;   // K range per blockIdx.y slice (split-K), multiple of 32
 };
 
 __device__ __forceinline__ int x3_lds_off(int row, int chunk) {
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   const int64_t tiles_n = (g.N + kX3BN - 1) / kX3BN;
   const int64_t m0 = ((int64_t)blockIdx.x / tiles_n) * kX3BM;
   const int64_t n0 = ((int64_t)blockIdx.x % tiles_n) * kX3BN;
-  const int nk = (int)((g.K + kX3BK - 1) / kX3BK);
+  const int z = blockIdx.y;
+  const int64_t k_begin = (int64_t)z * g.k_chunk;
+  const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
+  const int nk = (int)((k_end - k_begin + kX3BK - 1) / kX3BK);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[4], rb[4];
-  x3_stage_load(g.A, g.lda, m0, g.M, 0, g.K, tid, ra);
-  x3_stage_load(g.B, g.ldb, n0, g.N, 0, g.K, tid, rb);
+  x3_stage_load(g.A, g.lda, m0, g.M, k_begin, k_end, tid, ra);
+  x3_stage_load(g.B, g.ldb, n0, g.N, k_begin, k_end, tid, rb);
   x3_stage_store(lds[0][0], lds[0][1], tid, ra);
   x3_stage_store(lds[0][2], lds[0][3], tid, rb);
   __syncthreads();
@@ -118,9 +122,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = (kt + 1 < nk);
     if (more) {
-      const int64_t k0 = (int64_t)(kt + 1) * kX3BK;
-      x3_stage_load(g.A, g.lda, m0, g.M, k0, g.K, tid, ra);
-      x3_stage_load(g.B, g.ldb, n0, g.N, k0, g.K, tid, rb);
+      const int64_t k0 = k_begin + (int64_t)(kt + 1) * kX3BK;
+      x3_stage_load(g.A, g.lda, m0, g.M, k0, k_end, tid, ra);
+      x3_stage_load(g.B, g.ldb, n0, g.N, k0, k_end, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row =
             m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], 0);
+        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], z);
       }
     }
   }
@@ -185,21 +189,49 @@ static inline bool gemm_x3_usable(const float* A, int64_t lda, const float* B,
   return gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb);
 }
 
+// k_slices > 1 => split-K: the epilogue receives the slice index (EpiSlab).
 template <class Epi>
 static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
                           int64_t ldb, int64_t M, int64_t N, int64_t K,
-                          Epi epi, hipStream_t st) {
+                          Epi epi, hipStream_t st, int k_slices = 1) {
   if (M <= 0 || N <= 0) return VTC_OK;
-  GemmX3Args g{A, B, M, N, K, lda, ldb};
+  if (k_slices < 1) k_slices = 1;
+  int64_t chunk = ceil_div(ceil_div(K, k_slices), kX3BK) * kX3BK;
+  if (chunk < kX3BK) chunk = kX3BK;
+  GemmX3Args g{A, B, M, N, K, lda, ldb, chunk};
   const int64_t tiles = ceil_div(M, kX3BM) * ceil_div(N, kX3BN);
   if (tiles > 0x7fffffffLL) {
     set_error("gemm_x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((gemm_x3_kernel<Epi>), dim3((unsigned)tiles), dim3(256),
-                     0, st, g, epi);
+  hipLaunchKernelGGL((gemm_x3_kernel<Epi>),
+                     dim3((unsigned)tiles, (unsigned)ceil_div(K, chunk)),
+                     dim3(256), 0, st, g, epi);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
+
+// slices actually launched for (K, k_slices)
+static inline int gemm_x3_slices(int64_t K, int k_slices) {
+  if (k_slices < 1) k_slices = 1;
+  int64_t chunk = ceil_div(ceil_div(K, k_slices), kX3BK) * kX3BK;
+  if (chunk < kX3BK) chunk = kX3BK;
+  return (int)ceil_div(K, chunk);
+}
+
+// how many K slices give a contraction with few output tiles enough blocks
+static inline int gemm_x3_want_slices(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ceil_div(M, kX3BM) * ceil_div(N, kX3BN);
+  int64_t want = ceil_div(1024, tiles);
+  const int64_t cap = ceil_div(K, 256);
+  if (want > cap) want = cap;
+  if (want > 16) want = 16;
+  if (want < 1) want = 1;
+  return gemm_x3_slices(K, (int)want);
+}
+
+// out = sum_z slabs[z] - X   (fixed order; the residual of a split-K product)
+int launch_slab_reduce_minus(const float* slabs, int slices, int64_t count,
+                             const float* X, float* out, hipStream_t st);
 
 }  // namespace vtc
