@@ -111,6 +111,24 @@ def test_alignment_gradient_with_shared_atoms(device, plugins):
   assert helpers.rel_err(D.cpu().numpy(), ref.numpy()) < helpers.REL_TOL_DICT
 
 
+def test_bf16x3_early_stopping(device, plugins):
+  """Early stopping with the proximal step fused into the product epilogue:
+  same iteration count and codes as the oracle."""
+  sub = plugins[0]
+  m, num_groups, n = 4, 24, 64
+  groups = [list(range(g * m, g * m + m)) for g in range(num_groups)]
+  Xn = helpers.gaussian_patches(610, 70, n)
+  Dn = helpers.unit_rows(611, num_groups * m, n)
+  ref = sc_oracle.subspace_ista_fista(torch.from_numpy(Xn),
+                                      torch.from_numpy(Dn), groups, 0.03, 200,
+                                      early_stopping_epsilon=5e-3)
+  out = sub.run(helpers.to_dev(Xn, device), helpers.to_dev(Dn, device), groups,
+                0.03, 200, early_stopping_epsilon=5e-3, precision='bf16x3')
+  assert 1 < sub.run.last_iters < 200
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                             'bf16x3 early stop', max_flip_mag=1e-4)
+
+
 def test_bf16x3_contraction_matches_reference(device, plugins):
   """The tiled bf16 hi/lo split contraction on the subspace path."""
   sub = plugins[0]
@@ -130,17 +148,21 @@ def test_bf16x3_contraction_matches_reference(device, plugins):
     sub.run(X, D, groups, 0.008, 5, precision='bf16')
 
 
-@pytest.mark.parametrize('m,precision', [(3, 'f32'), (5, 'f32'), (2, 'f32'),
-                                         (1, 'f32'), (16, 'bf16x3')])
+@pytest.mark.parametrize('m,precision', [
+    (3, 'f32'), (5, 'f32'), (2, 'f32'), (1, 'f32'), (16, 'bf16x3'),
+    (1, 'bf16x3'), (2, 'bf16x3'), (4, 'bf16x3'), (8, 'bf16x3'),
+    (32, 'bf16x3'), (12, 'bf16x3'), (64, 'bf16x3')])
 def test_group_sizes_against_oracle(device, plugins, m, precision):
-  """Power-of-two group sizes take the coalesced shuffle kernel, the others
-  the thread-per-group kernel; both against the oracle."""
+  """f32: power-of-two group sizes take the coalesced shuffle kernel, the
+  others the thread-per-group kernel.  bf16x3: powers of two up to 32 run the
+  proximal step in the epilogue of the gradient product, the others the
+  separate kernels.  All against the oracle."""
   sub = plugins[0]
   num_groups = 12
   s_atoms, n = num_groups * m, 64
   if precision == 'bf16x3':
-    s_atoms, n = 16 * 16, 64
-    num_groups = 16
+    num_groups = 20 if m <= 16 else 5   # slots not a multiple of the 128 tile
+    s_atoms = num_groups * m
   groups = [list(range(g * m, g * m + m)) for g in range(num_groups)]
   Xn = helpers.gaussian_patches(500 + m, 40, n)
   Dn = helpers.unit_rows(501 + m, s_atoms, n)

@@ -20,7 +20,21 @@
 #include "common.h"
 #include "gemm_f32.h"
 
+#include <type_traits>
+
 namespace vtc {
+
+// An epilogue that declares `static constexpr bool kWholeTile` receives each
+// 32x32 accumulator tile at once through
+//   tile(row0, col0, lane, acc, rows, cols)
+// (lane l holds column col0 + (l & 31), register r holds row
+//  row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)), every lane of the wave
+// calling it, so it may combine columns with lane shuffles.
+template <class E, class = void>
+struct epi_whole_tile : std::false_type {};
+template <class E>
+struct epi_whole_tile<E, std::void_t<decltype(E::kWholeTile)>>
+    : std::true_type {};
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
@@ -167,16 +181,25 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
     cur ^= 1;
   }
 
+  if constexpr (epi_whole_tile<Epi>::value) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t col = n0 + wn * 64 + ni * 32 + l31;
+      for (int ni = 0; ni < 2; ++ni)
+        epi.tile(m0 + wm * 64 + mi * 32, n0 + wn * 64 + ni * 32, lane,
+                 acc[mi][ni], g.M, g.N);
+  } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row =
-            m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], z);
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int64_t col = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row =
+              m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], z);
+        }
       }
     }
   }

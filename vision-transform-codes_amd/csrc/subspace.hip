@@ -31,6 +31,75 @@ struct EpiGradStep {  // Y <- Y - eta * g
   __device__ __forceinline__ void block_end() const {}
 };
 
+// Gradient step and group proximal step in the epilogue of the R Dg^T product
+// (bf16x3 path, group size a power of two <= 32): the m slots of a group are m
+// adjacent columns, i.e. m adjacent lanes of the accumulator tile, so the
+// group norm is a lane-shuffle tree and the (b, slots) state is read and
+// written once per iteration instead of three times.
+template <int M>
+struct EpiGroupProx {
+  static constexpr bool kWholeTile = true;
+  float* Y;
+  float* C;
+  int64_t ld;
+  float eta, cutoff, beta;
+  int fista;
+  double* delta_sum;
+  double local;
+  __device__ __forceinline__ void tile(int64_t row0, int64_t col0, int lane,
+                                       const f32x16& acc, int64_t rows,
+                                       int64_t cols) {
+    const int64_t col = col0 + (lane & 31);
+    const bool col_ok = col < cols;
+    const int64_t rbase = row0 + 4 * (lane >> 5);
+    float y[16], c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+      const bool ok = col_ok && row < rows;
+      y[r] = ok ? Y[row * ld + col] : 0.f;
+      c[r] = ok ? C[row * ld + col] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+      const bool ok = col_ok && row < rows;
+      const float p = ok ? sub_rn(y[r], mul_rn(eta, acc[r])) : 0.f;
+      float sumsq = mul_rn(p, p);
+#pragma unroll
+      for (int off = 1; off < M; off <<= 1)
+        sumsq = add_rn(sumsq, __shfl_xor(sumsq, off, 64));
+      float norm = sqrtf(sumsq);
+      if (norm == 0.f) norm = 1.f;  // subspace_ista_fista.py:150
+      const float scale = clamp_min0(sub_rn(1.f, cutoff / norm));
+      const float cn = mul_rn(p, scale);
+      const float d = sub_rn(cn, c[r]);
+      if (ok) {
+        Y[row * ld + col] = fista ? add_rn(cn, mul_rn(beta, d)) : cn;
+        C[row * ld + col] = cn;
+        if (delta_sum) local += (double)(fabsf(d) / eta);
+      }
+    }
+  }
+  __device__ __forceinline__ void operator()(int64_t, int64_t, float,
+                                             int) const {}
+  __device__ __forceinline__ void block_end() const {
+    if (delta_sum) {
+      const double w = wave_sum(local);
+      if ((threadIdx.x & 63) == 0) atomicAdd(delta_sum, w);
+    }
+  }
+};
+
+template <int M>
+static int launch_grad_prox_x3(const float* R, const float* Dg, float* Y,
+                               float* C, int64_t b, int64_t slots, int64_t n,
+                               float eta, float cutoff, float beta, int fista,
+                               double* delta_sum, hipStream_t st) {
+  EpiGroupProx<M> e{Y, C, slots, eta, cutoff, beta, fista, delta_sum, 0.0};
+  return launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st);
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ D,
                                    const int32_t* __restrict__ index,
                                    const uint8_t* __restrict__ valid,
@@ -387,13 +456,39 @@ extern "C" int vtc_subspace_ista_fista(
                                         slots, 1, e1, st);
     }
     if (rc != VTC_OK) return rc;
+    if (eps >= 0.f)
+      VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
+    const float beta_k = fista ? betas[k] : 0.f;
+    double* dsum = eps >= 0.f ? delta_sum : nullptr;
+    bool fused_prox = false;
+    if (x3) {
+#define VTC_FUSED_PROX(MM)                                                  \
+  case MM:                                                                  \
+    rc = launch_grad_prox_x3<MM>(R, grouped_dictionary, Y, grouped_codes,   \
+                                 b, slots, n, eta, cutoff, beta_k,          \
+                                 fista ? 1 : 0, dsum, st);                  \
+    fused_prox = true;                                                      \
+    break;
+      switch (m) {
+        VTC_FUSED_PROX(1)
+        VTC_FUSED_PROX(2)
+        VTC_FUSED_PROX(4)
+        VTC_FUSED_PROX(8)
+        VTC_FUSED_PROX(16)
+        VTC_FUSED_PROX(32)
+        default: break;
+      }
+#undef VTC_FUSED_PROX
+      if (fused_prox) {
+        if (rc != VTC_OK) return rc;
+      }
+    }
+    if (!fused_prox) {
     EpiGradStep e2{Y, slots, eta};
     rc = x3 ? launch_gemm_x3(R, n, grouped_dictionary, n, b, slots, n, e2, st)
             : launch_gemm_f32<true, true>(R, n, grouped_dictionary, n, b,
                                           slots, n, 1, e2, st);
     if (rc != VTC_OK) return rc;
-    if (eps >= 0.f)
-      VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     if (!launch_group_prox_pow2(Y, grouped_codes, b, groups, (int)m, cutoff,
                                 fista ? betas[k] : 0.f, fista ? 1 : 0, eta,
                                 eps >= 0.f ? delta_sum : nullptr, st))
@@ -402,6 +497,7 @@ extern "C" int vtc_subspace_ista_fista(
                          cutoff, fista ? betas[k] : 0.f, fista ? 1 : 0, eta,
                          eps >= 0.f ? delta_sum : nullptr);
     VTC_LAUNCH_CHECK();
+    }
     done = k + 1;
     if (eps >= 0.f) {
       double total = 0.0;
