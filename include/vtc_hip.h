@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VTC_ABI_VERSION 1
+#define VTC_ABI_VERSION 2
 
 enum vtc_status {
   VTC_OK = 0,
@@ -150,14 +150,20 @@ typedef struct vtc_conv_geometry {
 int vtc_conv_code_dims(const vtc_conv_geometry* g, int32_t* code_h,
                        int32_t* code_w);
 size_t vtc_conv_ista_fista_workspace_bytes(const vtc_conv_geometry* g);
-/* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w) */
+/* 1 when the geometry has a VTC_BF16X3 path: one channel, stride 1, square
+ * kernels of 5, 8, 11 or 16, operand planes within the 160 KiB LDS. */
+int vtc_conv_x3_supported(const vtc_conv_geometry* g);
+/* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w).
+ * precision: VTC_F32 (direct f32 convolutions, fixed summation order) or
+ * VTC_BF16X3 (both convolutions as bf16 hi/lo split MFMA contractions;
+ * VTC_ERR_UNSUPPORTED unless vtc_conv_x3_supported). */
 int vtc_conv_ista_fista(const float* images_padded, const float* dictionary,
                         const float* initial_codes, float* codes,
                         const vtc_conv_geometry* g, float stepsize,
                         float sparsity_weight, int num_iters, int variant,
                         int threshold, float early_stopping_epsilon,
-                        void* workspace, size_t workspace_bytes,
-                        int* iters_run, void* stream);
+                        int precision, void* workspace,
+                        size_t workspace_bytes, int* iters_run, void* stream);
 
 /* ---- dictionary update, fully-connected (rows a5, a6, a7) --------------- */
 size_t vtc_fc_dict_gradient_workspace_bytes(int64_t b, int64_t n, int64_t s);

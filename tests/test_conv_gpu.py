@@ -138,3 +138,117 @@ def test_unit_stride_specialisations(device, plugins, k, c, s, height, width):
                helpers.to_dev(ref.numpy(), device), (1, 1), padding,
                stepsize=0.005)
   assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
+
+
+def _conv_case(seed, k, s, height, width, b=2, scale=0.5):
+  rs = np.random.RandomState(seed)
+  pad = k - 1
+  imgs = np.zeros((b, 1, height + 2 * pad, width + 2 * pad), np.float32)
+  imgs[:, :, pad:pad + height, pad:pad + width] = (
+      scale * rs.randn(b, 1, height, width)).astype(np.float32)
+  D = rs.randn(s, 1, k, k).astype(np.float32)
+  D /= np.sqrt((D.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[
+      :, None, None, None].astype(np.float32)
+  return imgs, D, ((pad, pad), (pad, pad))
+
+
+@pytest.mark.parametrize('k,s,height,width', [(11, 32, 70, 93),
+                                              (11, 128, 48, 60),
+                                              (11, 9, 64, 64),
+                                              (5, 40, 41, 130),
+                                              (8, 64, 50, 77),
+                                              (16, 20, 48, 80)])
+def test_bf16x3_matrix_core_path(device, plugins, k, s, height, width):
+  """Stride-1 one-channel geometries with precision='bf16x3': both
+  convolutions as split-bf16 MFMA contractions (conv_x3.h).  Tile-ragged image
+  sizes, kernel counts that are not multiples of 16/32/64, all kernel sizes
+  instantiated; against the oracle at the tolerance of the f32 path
+  (relative 2e-5 on the codes, support flips only below 1e-5).
+
+  Two regimes: the reference's own step 1/lambda_max(F F^T), which for
+  stride 1 is far above 1/L of the convolution operator and makes the
+  iterates grow (8 iterations), and a step of 0.9/s, for which FISTA converges
+  to a sparse code (25 iterations)."""
+  conv = plugins[0]
+  imgs, D, padding = _conv_case(2000 + k + s, k, s, height, width)
+  X, Dd = helpers.to_dev(imgs, device), helpers.to_dev(D, device)
+  eta = sc_oracle.conv_stepsize(torch.from_numpy(D))
+  for step, iters in ((float(eta), 8), (0.9 / s, 25)):
+    ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs),
+                                    torch.from_numpy(D), (1, 1), padding, 0.05,
+                                    iters, stepsize=step)
+    codes = conv.run(X, Dd, (1, 1), padding, 0.05, iters, stepsize=step,
+                     precision='bf16x3')
+    helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), 2e-5,
+                               'bf16x3 k=%d s=%d step=%g' % (k, s, step),
+                               max_flip_mag=1e-5)
+
+
+def test_bf16x3_modes_and_reproducibility(device, plugins):
+  """Threshold modes, ISTA, warm start and early stopping on the bf16x3 path
+  (convergent step); two runs give bit-identical codes (the LDS accumulation
+  of the synthesis is ordered)."""
+  conv = plugins[0]
+  imgs, D, padding = _conv_case(77, 11, 48, 40, 52)
+  Xc, Dc = torch.from_numpy(imgs), torch.from_numpy(D)
+  X, Dd = helpers.to_dev(imgs, device), helpers.to_dev(D, device)
+  eta = 0.02
+  for kw in ({'nonnegative_only': True}, {'hard_threshold': True},
+             {'nonnegative_only': True, 'hard_threshold': True},
+             {'variant': 'ista'}):
+    iters = 1 if kw.get('hard_threshold') else 20
+    ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, iters,
+                                    stepsize=eta, **kw)
+    out = conv.run(X, Dd, (1, 1), padding, 0.05, iters, stepsize=eta,
+                   precision='bf16x3', **kw)
+    if kw.get('hard_threshold'):
+      # a hard threshold is discontinuous: an entry within rounding distance
+      # of the cutoff (lambda*eta = 1e-3) flips between 0 and ~1e-3 and moves
+      # its neighbours in later iterations, where the difference is then no
+      # longer small (hence a single iteration here; bf16x3 results differ
+      # from f32 ones by ~1e-5 relative, enough for a few such flips among
+      # 3e5 entries).  Flips must sit at the cutoff.
+      helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-3,
+                                 'bf16x3 %r' % kw, max_flip_mag=1.1e-3)
+    else:
+      helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                                 'bf16x3 %r' % kw, max_flip_mag=1e-5)
+  warm = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 3,
+                                   stepsize=eta)
+  ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 4,
+                                  stepsize=eta, initial_codes=warm)
+  a = conv.run(X, Dd, (1, 1), padding, 0.05, 4, stepsize=eta,
+               initial_codes=helpers.to_dev(warm.numpy(), device),
+               precision='bf16x3')
+  b = conv.run(X, Dd, (1, 1), padding, 0.05, 4, stepsize=eta,
+               initial_codes=helpers.to_dev(warm.numpy(), device),
+               precision='bf16x3')
+  helpers.assert_codes_match(a.cpu().numpy(), ref.numpy(), 2e-5,
+                             'bf16x3 warm start', max_flip_mag=1e-5)
+  assert torch.equal(a, b)
+  ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 300,
+                                  stepsize=eta, early_stopping_epsilon=6e-3)
+  out = conv.run(X, Dd, (1, 1), padding, 0.05, 300, stepsize=eta,
+                 early_stopping_epsilon=6e-3, precision='bf16x3')
+  assert 20 < conv.run.last_iters < 40
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                             'bf16x3 early stop', max_flip_mag=1e-5)
+
+
+def test_bf16x3_unsupported_geometry(device, plugins):
+  """Strided or multi-channel geometries have no bf16x3 path: explicit
+  request fails, 'auto' falls back to the direct f32 kernels."""
+  conv = plugins[0]
+  rs = np.random.RandomState(5)
+  imgs = (0.5 * rs.randn(1, 2, 40, 40)).astype(np.float32)
+  D = rs.randn(4, 2, 8, 8).astype(np.float32)
+  D /= np.sqrt((D ** 2).sum(axis=(1, 2, 3)))[:, None, None, None]
+  with pytest.raises(NotImplementedError):
+    conv.run(helpers.to_dev(imgs, device), helpers.to_dev(D, device), (4, 4),
+             None, 0.05, 2, precision='bf16x3')
+  out = conv.run(helpers.to_dev(imgs, device), helpers.to_dev(D, device),
+                 (4, 4), None, 0.05, 2, precision='auto')
+  ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D),
+                                  (4, 4), None, 0.05, 2)
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                             'auto fallback', max_flip_mag=1e-5)

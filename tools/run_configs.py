@@ -60,13 +60,15 @@ def conv(dev):
   D /= np.sqrt((D ** 2).sum(axis=(1, 2, 3)))[:, None, None, None]
   X, D = torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev)
   padding = ((pad, pad), (pad, pad))
-  dt, codes = timed(lambda: ista_fista.run(X, D, (1, 1), padding, 0.02, iters))
   flop_iter = 4.0 * s * k * k * 266 * 266
-  print('config 5 conv: b=%d  %d-iter conv FISTA  %.1f ms  = %.2f ms/image-iter'
-        '  %.2f TFLOP/s  nnz %.3f' % (
-            b, iters, dt * 1e3, dt * 1e3 / (b * iters),
-            flop_iter * b * iters / dt / 1e12,
-            float((codes != 0).float().mean())))
+  for prec in ('f32', 'bf16x3'):
+    dt, codes = timed(lambda: ista_fista.run(X, D, (1, 1), padding, 0.02,
+                                             iters, precision=prec))
+    print('config 5 conv [%s]: b=%d  %d-iter conv FISTA  %.1f ms  = %.3f '
+          'ms/image-iter  %.2f TFLOP/s  nnz %.3f' % (
+              prec, b, iters, dt * 1e3, dt * 1e3 / (b * iters),
+              flop_iter * b * iters / dt / 1e12,
+              float((codes != 0).float().mean())))
   dt, _ = timed(lambda: sc_steepest_descent.run(X, D, codes, (1, 1), padding,
                                                 stepsize=0.005))
   print('          conv dictionary update: %.2f ms' % (dt * 1e3))

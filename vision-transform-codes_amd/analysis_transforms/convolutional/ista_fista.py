@@ -18,12 +18,16 @@ from utils import convolutions
 def run(images_padded, dictionary, kernel_stride, padding_dims,
         sparsity_weight, num_iters, variant='fista', initial_codes=None,
         early_stopping_epsilon=None, nonnegative_only=False,
-        hard_threshold=False, stepsize=None):
+        hard_threshold=False, stepsize=None, precision=None):
   """
   images_padded (b, c, h, w), dictionary (s, c, kh, kw): float32 on a HIP
   device.  kernel_stride (sv, sh); padding_dims ((lead_v, trail_v),
   (lead_h, trail_h)) or None.  Returns codes (b, s, code_h, code_w).
-  `stepsize` is an extension (skip the eigen-solve).
+  Extensions: `stepsize` (skip the eigen-solve) and `precision` in {None,
+  'auto', 'f32', 'bf16x3'}.  'bf16x3' runs both convolutions as bf16 hi/lo
+  split contractions on the matrix cores (one channel, stride 1, square
+  kernels of 5/8/11/16); 'auto' picks it where it applies and the direct f32
+  kernels elsewhere.
   """
   assert variant in ['ista', 'fista']
   lib = vtc_hip.load_library()
@@ -61,13 +65,20 @@ def run(images_padded, dictionary, kernel_stride, padding_dims,
   iters_run = ctypes.c_int(0)
   eps = -1.0 if early_stopping_epsilon is None else float(
       early_stopping_epsilon)
+  name = precision if precision is not None else (
+      vtc_hip.get_default_precision())
+  if name == 'auto':
+    name = 'bf16x3' if (geom.s >= 32 and lib.vtc_conv_x3_supported(
+        ctypes.byref(geom))) else 'f32'
+  if name == 'bf16':
+    raise NotImplementedError('convolutional inference has no bf16 fast mode')
   vtc_hip.check(lib.vtc_conv_ista_fista(
       vtc_hip.ptr(images_padded), vtc_hip.ptr(dictionary),
       vtc_hip.ptr(initial_codes), vtc_hip.ptr(codes), ctypes.byref(geom),
       float(stepsize), float(sparsity_weight), int(num_iters),
       vtc_hip.variant_code(variant),
       vtc_hip.threshold_mode(nonnegative_only, hard_threshold), eps,
-      vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run),
+      vtc_hip.PRECISIONS[name], vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run),
       vtc_hip.current_stream(device)), 'vtc_conv_ista_fista')
   run.last_iters = iters_run.value
   return codes

@@ -213,6 +213,7 @@ struct ProxParams {
 
 }  // namespace vtc
 #include "conv_unit.h"
+#include "conv_x3.h"
 namespace vtc {
 
 __global__ __launch_bounds__(256) void conv_analysis_prox_kernel(
@@ -427,6 +428,11 @@ __global__ __launch_bounds__(1024) void conv_apply_kernel(
   }
 }
 
+static size_t conv_x3_image_bytes(const ConvGeo& g) {
+  CxPlan p;
+  return cx_plan(g, &p) ? cx_image_bytes(p) : 0;
+}
+
 static size_t conv_inference_ws(const ConvGeo& g) {
   const size_t code_elems = (size_t)g.b * g.s * g.ch * g.cw;
   const size_t img_elems = (size_t)g.b * g.c * g.H * g.W;
@@ -434,6 +440,7 @@ static size_t conv_inference_ws(const ConvGeo& g) {
          align_up(8 * img_elems * sizeof(float), 256) +       // residual or
                                                               // <= 8 partials
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
+         conv_x3_image_bytes(g) +                             // bf16x3 operands
          256;
 }
 
@@ -472,6 +479,13 @@ extern "C" int vtc_conv_code_dims(const vtc_conv_geometry* g, int32_t* code_h,
   return VTC_OK;
 }
 
+extern "C" int vtc_conv_x3_supported(const vtc_conv_geometry* geom) {
+  ConvGeo g;
+  CxPlan p;
+  if (!geom || make_geo(geom, &g) != VTC_OK) return 0;
+  return cx_plan(g, &p) ? 1 : 0;
+}
+
 extern "C" size_t vtc_conv_ista_fista_workspace_bytes(
     const vtc_conv_geometry* geom) {
   ConvGeo g;
@@ -483,13 +497,23 @@ extern "C" int vtc_conv_ista_fista(
     const float* images_padded, const float* dictionary,
     const float* initial_codes, float* codes, const vtc_conv_geometry* geom,
     float stepsize, float sparsity_weight, int num_iters, int variant,
-    int threshold, float early_stopping_epsilon, void* workspace,
-    size_t workspace_bytes, int* iters_run, void* stream) {
+    int threshold, float early_stopping_epsilon, int precision,
+    void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
   VTC_REQUIRE(images_padded && dictionary && codes,
               "vtc_conv_ista_fista: null pointer");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
+              "vtc_conv_ista_fista: precision must be VTC_F32 or VTC_BF16X3");
   ConvGeo g;
   int rc = make_geo(geom, &g);
   if (rc != VTC_OK) return rc;
+  CxPlan xp;
+  const bool x3 = (precision == VTC_BF16X3);
+  if (x3 && !cx_plan(g, &xp)) {
+    set_error("vtc_conv_ista_fista: bf16x3 covers one channel, stride 1 and "
+              "square kernels of 5, 8, 11 or 16 (see "
+              "vtc_conv_x3_supported)");
+    return VTC_ERR_UNSUPPORTED;
+  }
   VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
               "vtc_conv_ista_fista: variant must be ista or fista");
   VTC_REQUIRE(threshold >= VTC_SOFT && threshold <= VTC_HARD_NONNEG,
@@ -509,6 +533,14 @@ extern "C" int vtc_conv_ista_fista(
   float* Ybuf = ws.take<float>(code_elems);
   float* residual = ws.take<float>(8 * img_elems);
   float* Kt = ws.take<float>((size_t)g.s * ctaps);
+  uint16_t* syn_image = nullptr;
+  uint16_t* ana_image = nullptr;
+  if (x3) {
+    syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
+    ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
+    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
+    if (rc != VTC_OK) return rc;
+  }
   double* delta_sum = ws.take<double>(1);
   const bool fista = (variant == VTC_FISTA);
   float* Y = fista ? Ybuf : codes;
@@ -549,7 +581,12 @@ extern "C" int vtc_conv_ista_fista(
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     ProxParams pp{eta, cutoff, fista ? betas[k] : 0.f, threshold,
                   fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr};
-    if (unit_path) {
+    if (x3) {
+      rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
+      if (rc != VTC_OK) return rc;
+      rc = cx_launch_analysis(residual, ana_image, Y, codes, g, xp, pp, st);
+      if (rc != VTC_OK) return rc;
+    } else if (unit_path) {
       // stride-1 square kernels: scalar-tap kernels, the kernel sum of the
       // synthesis split over `syn_groups` blocks per tile
       rc = launch_synth_unit(Y, dictionary, images_padded, residual, g,

@@ -1,0 +1,546 @@
+// Unit-stride, single-channel convolutional ISTA/FISTA on the bf16 matrix pipe
+// with split operands ("bf16x3": hi = bf16(x), lo = bf16(x - hi), product
+// hi*hi + hi*lo + lo*hi accumulated in f32 -- float32-level accuracy, see
+// gemm_x3.h).  BASELINE configs[4]: 128 kernels of 11x11 on 256x256 images.
+//
+// Restates analysis_transforms/convolutional/ista_fista.py:152-155 as two
+// contractions per iteration, neither with an im2col buffer in HBM:
+//
+//   synthesis  Q[tap, (u,v)] = sum_s D[s,tap] * Y[s,u,v]        M=taps N=pos K=s
+//              recon[y,x]    = sum_tap Q[tap, (y-dy, x-dx)]     ("col2im")
+//   analysis   G[s, (u,v)]   = sum_(dy,dx) D[s,dy,dx] * r[u+dy, v+dx]
+//                                                     M=atoms N=pos K=(dy,16 dx)
+//
+// In both, the accumulator tile's lanes run along v (code columns), so code
+// rows are read and written as 128-byte segments.
+//
+// Synthesis: a block owns a TH x TW tile of the residual image.  Each of its
+// 8 waves takes code rows u = y0-(K-1)+wave, +8, ..., forms Q for 64 code
+// columns and adds it into ITS OWN copy of the tile in LDS (ds_add_f32).  The
+// kernel taps are ordered over the accumulator rows so that the two half-waves
+// of one ds_add never touch the same pixel; a wave's adds are then ordered by
+// program order, the 8 copies are summed in wave order, and the result is
+// bitwise reproducible.  The Y operand goes from HBM straight into MFMA
+// operand registers (a lane holds 8 atoms of one code position).
+//
+// Analysis: the residual window of the tile is split once into bf16 hi/lo
+// planes in LDS; a lane's operand is 8 consecutive pixels of a window row (an
+// unaligned 16-byte LDS read).  The gradient step, threshold and FISTA
+// extrapolation run on the accumulator tile: Y and the codes are read and
+// written once per iteration.
+#pragma once
+
+namespace vtc {
+
+typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kCxStrip = 64;       // code columns per wave unit (2 MFMA tiles)
+constexpr int kCxSynWaves = 8;
+constexpr int kCxSynRows = 4;      // code rows per wave (synthesis)
+constexpr int kCxAnaRows = 8;      // code rows per block (analysis)
+constexpr int kCxAnaPitch = 88;    // window row pitch, bf16 elements
+
+template <int K>
+struct CxDims {
+  static constexpr int TAPS = K * K;
+  static constexpr int HROWS = (K + 1) / 2;         // tap rows per half-wave
+  static constexpr int HTAPS = HROWS * K;
+  static constexpr int MT = (HTAPS + 15) / 16;      // 32-row operand tiles
+  static constexpr int SLOTS = 32 * MT;
+  static constexpr int TW = kCxStrip - (K - 1);
+  static constexpr int TH = kCxSynWaves * kCxSynRows - (K - 1);
+  static constexpr int PW = TW + 1;                 // private tile pitch
+  static constexpr int NI = (MT <= 4) ? 2 : 1;      // column tiles per pass
+};
+
+// Accumulator row -> kernel tap.  In the 32x32 accumulator layout register r
+// of lanes 0-31 is row rho = (r & 3) + 8 (r >> 2), of lanes 32-63 row rho + 4.
+// Rows with bit 2 clear take taps idx = 0 .. HTAPS-1 (tap rows 0 .. HROWS-1,
+// row-major), the row 4 further on takes the tap HROWS tap-rows below it:
+//   m = 32 mt + rho + 4 h   ->   idx = 16 mt + r,   tap = idx + h * HTAPS
+// so the two half-waves of one accumulator register always sit on different
+// image rows (no two lanes of a ds_add share a pixel) and their pixel offsets
+// differ by the constant HROWS * pitch, which goes into the lane's base.
+// Returns -1 for a row without a tap (its operand row is zero).
+__host__ __device__ inline int cx_slot_tap(int m, int k) {
+  const int hrows = (k + 1) / 2, htaps = hrows * k;
+  const int idx = ((m >> 3) << 2) | (m & 3);
+  if (idx >= htaps) return -1;
+  const int t = idx + ((m >> 2) & 1) * htaps;
+  return t < k * k ? t : -1;
+}
+
+__device__ __forceinline__ uint16_t cx_bits(__bf16 v) {
+  return __builtin_bit_cast(uint16_t, v);
+}
+
+// ------------------------------------------------------------------ pack
+// syn image (uint16): [plane][slot][s16 + 8]      D[s][tap(slot)], k = s
+// ana image (uint16): [chunk][plane][dy][AC][16]  D[chunk*AC + a][dy][dx]
+__global__ void conv_x3_pack_kernel(const float* __restrict__ D,
+                                    uint16_t* __restrict__ syn,
+                                    uint16_t* __restrict__ ana, int s, int k,
+                                    int s16, int slots, int AC, int chunks) {
+  const int taps = k * k;
+  const int pitch = s16 + 8;
+  const int64_t syn_plane = (int64_t)slots * pitch;
+  const int64_t ana_plane = (int64_t)k * AC * 16;
+  const int64_t total = syn_plane + (int64_t)chunks * ana_plane;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += stride) {
+    float v = 0.f;
+    uint16_t *hi, *lo;
+    if (e < syn_plane) {
+      const int slot = (int)(e / pitch), a = (int)(e % pitch);
+      const int t = cx_slot_tap(slot, k);
+      if (a < s && t >= 0) v = D[(int64_t)a * taps + t];
+      hi = syn + e;
+      lo = syn + syn_plane + e;
+    } else {
+      const int64_t f = e - syn_plane;
+      const int chunk = (int)(f / ana_plane);
+      const int rem = (int)(f % ana_plane);
+      const int dy = rem / (AC * 16), a = chunk * AC + (rem / 16) % AC,
+                dx = rem % 16;
+      if (a < s && dx < k) v = D[(int64_t)a * taps + dy * k + dx];
+      hi = ana + (int64_t)chunk * 2 * ana_plane + rem;
+      lo = hi + ana_plane;
+    }
+    const __bf16 h = (__bf16)v;
+    *hi = cx_bits(h);
+    *lo = cx_bits((__bf16)(v - (float)h));
+  }
+}
+
+// registers -> one MFMA operand pair
+__device__ __forceinline__ void cx_split8(const float (&v)[8], cx_bf16x8& hi,
+                                          cx_bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (__bf16)v[j];
+    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+  }
+}
+
+// ------------------------------------------------------------- synthesis
+template <int K>
+__global__ __launch_bounds__(512) void conv_synth_x3_kernel(
+    const float* __restrict__ Y, const uint16_t* __restrict__ syn_image,
+    const float* __restrict__ X, float* __restrict__ R, ConvGeo g, int s16,
+    int tiles_x) {
+  using Dm = CxDims<K>;
+  constexpr int MT = Dm::MT, NI = Dm::NI, TH = Dm::TH, TW = Dm::TW,
+                PW = Dm::PW;
+  extern __shared__ __attribute__((aligned(16))) char cx_lds[];
+  char* lds = cx_lds;
+  const int pitch = s16 + 8;                       // elements per slot row
+  const int plane = Dm::SLOTS * pitch;             // elements per plane
+  const uint16_t* Dh = reinterpret_cast<const uint16_t*>(lds);
+  const uint16_t* Dl = Dh + plane;
+  float* priv = reinterpret_cast<float*>(lds + (size_t)plane * 4);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  {
+    const int n16 = plane / 4;                     // 2 planes * 2 B / 16 B
+    const uint4* src = reinterpret_cast<const uint4*>(syn_image);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+    for (int i = tid; i < kCxSynWaves * TH * PW; i += 512) priv[i] = 0.f;
+  }
+  __syncthreads();
+  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  const int64_t img = blockIdx.y;
+  const int x0 = tile_x * TW, y0 = tile_y * TH;
+  float* mine = priv + wave * TH * PW;
+  const int64_t map = (int64_t)g.ch * g.cw;
+  const float* Yimg = Y + img * g.s * map;
+  const int nks = s16 / 16;
+
+  // Y of this image as a buffer resource: a lane's operand is 8 atoms of one
+  // code position, i.e. 8 dword loads `map` elements apart; a column outside
+  // the code map gets an out-of-range offset, which reads as zero.
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Yimg, 0, (int)((int64_t)g.s * map * 4), 0x00020000);
+  const unsigned map4 = (unsigned)(map * 4);
+  const bool ragged = (g.s != s16);                // last K step has no atom
+
+  for (int ur = 0; ur < kCxSynRows; ++ur) {
+    const int u = y0 - (K - 1) + wave + kCxSynWaves * ur;
+    if (u < 0 || u >= g.ch) continue;              // whole wave
+#pragma unroll 1
+    for (int nb = 0; nb < 2; nb += NI) {
+      int vcol[NI];
+      unsigned voff[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        vcol[ni] = x0 - (K - 1) + 32 * (nb + ni) + l31;
+        const bool vok = vcol[ni] >= 0 && vcol[ni] < g.cw;
+        voff[ni] = vok ? (unsigned)(8 * half) * map4 +
+                             (unsigned)(u * g.cw + vcol[ni]) * 4u
+                       : 0x80000000u;
+      }
+      f32x16 acc[MT][NI];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][ni][r] = 0.f;
+
+      float cur[NI][8], nxt[NI][8];
+      auto fetch = [&](int ks, float (&dst)[NI][8]) {
+        const bool guard = ragged && ks + 1 == nks;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            unsigned vo = voff[ni];
+            if (guard && ks * 16 + 8 * half + j >= g.s) vo = 0x80000000u;
+            dst[ni][j] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(
+                           yrs, vo, (unsigned)(ks * 16 + j) * map4, 0));
+          }
+      };
+      fetch(0, cur);
+      for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 1 < nks) fetch(ks + 1, nxt);
+        cx_bf16x8 bh[NI], bl[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) cx_split8(cur[ni], bh[ni], bl[ni]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int off = (32 * mt + l31) * pitch + ks * 16 + 8 * half;
+          const cx_bf16x8 ah = __builtin_bit_cast(
+              cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
+          const cx_bf16x8 al = __builtin_bit_cast(
+              cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                ah, bh[ni], acc[mt][ni], 0, 0, 0);
+            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                ah, bl[ni], acc[mt][ni], 0, 0, 0);
+            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                al, bh[ni], acc[mt][ni], 0, 0, 0);
+          }
+        }
+        if (ks + 1 < nks) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cur[ni][j] = nxt[ni][j];
+        }
+      }
+      // col2im into this wave's copy of the tile.  Rows without a tap hold
+      // exact zeros (zero operand rows), so only the pixel range is tested.
+      const int pyb = u - y0 + half * Dm::HROWS;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int pxb = vcol[ni] - x0;
+        float* base = mine + pyb * PW + pxb;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = 16 * mt + r;               // compile time
+            if (idx >= Dm::HTAPS) continue;
+            const int dy = idx / K, dx = idx % K;
+            if ((unsigned)(pyb + dy) < (unsigned)TH &&
+                (unsigned)(pxb + dx) < (unsigned)TW)
+              __hip_atomic_fetch_add(base + dy * PW + dx, acc[mt][ni][r],
+                                     __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < TH * TW; e += 512) {
+    const int py = e / TW, px = e % TW;
+    const int y = y0 + py, x = x0 + px;
+    if (y >= g.H || x >= g.W) continue;
+    float sum = priv[py * PW + px];
+#pragma unroll
+    for (int w = 1; w < kCxSynWaves; ++w)
+      sum = add_rn(sum, priv[w * TH * PW + py * PW + px]);
+    const int64_t i = (img * g.H + y) * (int64_t)g.W + x;
+    R[i] = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+  }
+}
+
+// -------------------------------------------------------------- analysis
+struct __attribute__((packed, aligned(2))) CxUnaligned16 {
+  uint32_t x, y, z, w;
+};
+
+template <int MA>   // 32-atom tiles per block (atom chunk AC = 32 * MA)
+__global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
+    const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
+    float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
+    ProxParams pp) {
+  constexpr int AC = 32 * MA;
+  extern __shared__ __attribute__((aligned(16))) char cx_lds[];
+  char* lds = cx_lds;
+  const int k = g.kh;
+  const int plane = k * AC * 16;                   // elements
+  const int rows = kCxAnaRows + k - 1;
+  uint16_t* Dh = reinterpret_cast<uint16_t*>(lds);
+  uint16_t* Dl = Dh + plane;
+  uint16_t* Rh = Dl + plane;
+  uint16_t* Rl = Rh + rows * kCxAnaPitch;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int tile_v = blockIdx.x % tiles_v, tile_u = blockIdx.x / tiles_v;
+  const int chunk = blockIdx.y;
+  const int64_t img = blockIdx.z;
+  const int u0 = tile_u * kCxAnaRows, v0 = tile_v * kCxStrip;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(
+        ana_image + (int64_t)chunk * 2 * plane);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    const int n16 = plane / 4;
+    for (int i = tid; i < n16; i += 256) dst[i] = src[i];
+    const float* Rimg = R + img * g.H * (int64_t)g.W;
+    for (int e = tid; e < rows * kCxAnaPitch; e += 256) {
+      const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
+      const int y = u0 + ry, x = v0 + rx;
+      const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
+      const __bf16 h = (__bf16)v;
+      Rh[e] = cx_bits(h);
+      Rl[e] = cx_bits((__bf16)(v - (float)h));
+    }
+  }
+  __syncthreads();
+  const int64_t map = (int64_t)g.ch * g.cw;
+  const unsigned map4 = (unsigned)(map * 4);
+  const int code_bytes = (int)((int64_t)g.s * map * 4);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Y + img * g.s * map), 0, code_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(C + img * g.s * map), 0, code_bytes, 0x00020000);
+  const bool ragged = (g.s % AC) != 0;
+  double local = 0.0;
+  for (int pass = 0; pass < kCxAnaRows / 4; ++pass) {
+    const int lu = wave + 4 * pass;
+    const int u = u0 + lu;
+    if (u >= g.ch) continue;                       // whole wave
+    f32x16 acc[MA][2];
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ma][ni][r] = 0.f;
+    for (int dy = 0; dy < k; ++dy) {
+      cx_bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int off = (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
+        const CxUnaligned16 h =
+            *reinterpret_cast<const CxUnaligned16*>(Rh + off);
+        const CxUnaligned16 l =
+            *reinterpret_cast<const CxUnaligned16*>(Rl + off);
+        bh[ni] = __builtin_bit_cast(cx_bf16x8, h);
+        bl[ni] = __builtin_bit_cast(cx_bf16x8, l);
+      }
+#pragma unroll
+      for (int ma = 0; ma < MA; ++ma) {
+        const int off = ((dy * AC + 32 * ma + l31) * 16) + 8 * half;
+        const cx_bf16x8 ah = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
+        const cx_bf16x8 al = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bh[ni], acc[ma][ni], 0, 0, 0);
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bl[ni], acc[ma][ni], 0, 0, 0);
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              al, bh[ni], acc[ma][ni], 0, 0, 0);
+        }
+      }
+    }
+    // gradient step, threshold, extrapolation on the accumulator tile.
+    // Buffer addressing: lane offset (atom a0, row u, column v) + a scalar
+    // offset per register; positions outside the code map get an
+    // out-of-range offset (loads give 0, stores are dropped).
+#pragma unroll
+    for (int ma = 0; ma < MA; ++ma) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int v = v0 + 32 * ni + l31;
+        const int a0 = chunk * AC + 32 * ma + 4 * half;
+        const unsigned lane_off =
+            (unsigned)a0 * map4 + (unsigned)(u * g.cw + v) * 4u;
+        const bool col_ok = v < g.cw;
+        float yv[16], cv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          const bool ok = col_ok && (!ragged || a0 + rr < g.s);
+          const unsigned vo = ok ? lane_off : 0x80000000u;
+          yv[r] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(
+                         yrs, vo, (unsigned)rr * map4, 0));
+          cv[r] = 0.f;
+          if (pp.fista)
+            cv[r] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(
+                           crs, vo, (unsigned)rr * map4, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          const bool ok = col_ok && (!ragged || a0 + rr < g.s);
+          const unsigned vo = ok ? lane_off : 0x80000000u;
+          const float c = shrink(
+              sub_rn(yv[r], mul_rn(pp.eta, acc[ma][ni][r])), pp.cutoff,
+              pp.mode);
+          float d;
+          if (pp.fista) {
+            d = sub_rn(c, cv[r]);
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned,
+                                   add_rn(c, mul_rn(pp.beta, d))),
+                yrs, vo, (unsigned)rr * map4, 0);
+          } else {
+            d = sub_rn(c, yv[r]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(
+              __builtin_bit_cast(unsigned, c), crs, vo, (unsigned)rr * map4,
+              0);
+          if (pp.delta_sum && ok) local += (double)(fabsf(d) / pp.eta);
+        }
+      }
+    }
+  }
+  if (pp.delta_sum) {
+    const double w = wave_sum(local);
+    if ((tid & 63) == 0) atomicAdd(pp.delta_sum, w);
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct CxPlan {
+  int k, s16, slots, AC, chunks;
+  size_t syn_image_bytes, ana_image_bytes;
+  size_t syn_lds, ana_lds;
+  int th, tw;
+};
+
+template <int K>
+static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
+  using Dm = CxDims<K>;
+  p->k = K;
+  p->s16 = (g.s + 15) / 16 * 16;
+  p->slots = Dm::SLOTS;
+  p->AC = g.s > 32 ? 64 : 32;
+  p->chunks = (g.s + p->AC - 1) / p->AC;
+  p->syn_image_bytes = (size_t)2 * Dm::SLOTS * (p->s16 + 8) * 2;
+  p->ana_image_bytes = (size_t)p->chunks * 2 * K * p->AC * 16 * 2;
+  p->syn_lds = p->syn_image_bytes +
+               (size_t)kCxSynWaves * Dm::TH * Dm::PW * sizeof(float);
+  p->ana_lds = (size_t)2 * K * p->AC * 16 * 2 +
+               (size_t)2 * (kCxAnaRows + K - 1) * kCxAnaPitch * 2;
+  p->th = Dm::TH;
+  p->tw = Dm::TW;
+}
+
+// Geometries this path covers: one channel, stride 1, square kernels of the
+// sizes instantiated below, and operand planes that fit the 160 KiB LDS.
+static bool cx_plan(const ConvGeo& g, CxPlan* p) {
+  if (g.c != 1 || g.sv != 1 || g.sh != 1 || g.kh != g.kw) return false;
+  switch (g.kh) {
+    case 5: cx_fill_plan<5>(g, p); break;
+    case 8: cx_fill_plan<8>(g, p); break;
+    case 11: cx_fill_plan<11>(g, p); break;
+    case 16: cx_fill_plan<16>(g, p); break;
+    default: return false;
+  }
+  // 32-bit byte offsets within one image's code maps (buffer addressing)
+  const int64_t code_bytes = (int64_t)p->s16 * g.ch * g.cw * 4;
+  return p->syn_lds <= 150 * 1024 && p->ana_lds <= 150 * 1024 &&
+         g.b <= 65535 && code_bytes < (int64_t)0x7fffffff;
+}
+
+static size_t cx_image_bytes(const CxPlan& p) {
+  return align_up(p.syn_image_bytes, 256) + align_up(p.ana_image_bytes, 256);
+}
+
+static int cx_pack(const float* D, const ConvGeo& g, const CxPlan& p,
+                   uint16_t* syn, uint16_t* ana, hipStream_t st) {
+  hipLaunchKernelGGL(conv_x3_pack_kernel, dim3(256), dim3(256), 0, st, D, syn,
+                     ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+template <int K>
+static int cx_launch_synth_k(const float* Y, const uint16_t* syn,
+                             const float* X, float* R, const ConvGeo& g,
+                             const CxPlan& p, hipStream_t st) {
+  using Dm = CxDims<K>;
+  const int tiles_x = (int)ceil_div(g.W, Dm::TW);
+  const int tiles_y = (int)ceil_div(g.H, Dm::TH);
+  static bool attr_set = false;
+  if (!attr_set) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_synth_x3_kernel<K>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_synth_x3_kernel<K>,
+                     dim3((unsigned)(tiles_x * tiles_y), (unsigned)g.b),
+                     dim3(512), p.syn_lds, st, Y, syn, X, R, g, p.s16,
+                     tiles_x);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+static int cx_launch_synth(const float* Y, const uint16_t* syn, const float* X,
+                           float* R, const ConvGeo& g, const CxPlan& p,
+                           hipStream_t st) {
+  switch (p.k) {
+    case 5: return cx_launch_synth_k<5>(Y, syn, X, R, g, p, st);
+    case 8: return cx_launch_synth_k<8>(Y, syn, X, R, g, p, st);
+    case 11: return cx_launch_synth_k<11>(Y, syn, X, R, g, p, st);
+    case 16: return cx_launch_synth_k<16>(Y, syn, X, R, g, p, st);
+  }
+  set_error("conv bf16x3: kernel size not instantiated");
+  return VTC_ERR_UNSUPPORTED;
+}
+
+template <int MA>
+static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
+                                float* C, const ConvGeo& g, const CxPlan& p,
+                                const ProxParams& pp, hipStream_t st) {
+  const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
+  const int tiles_u = (int)ceil_div(g.ch, kCxAnaRows);
+  static bool attr_set = false;
+  if (!attr_set) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_analysis_x3_kernel<MA>,
+                     dim3((unsigned)(tiles_v * tiles_u), (unsigned)p.chunks,
+                          (unsigned)g.b),
+                     dim3(256), p.ana_lds, st, R, ana, Y, C, g, tiles_v, pp);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
+                              float* C, const ConvGeo& g, const CxPlan& p,
+                              const ProxParams& pp, hipStream_t st) {
+  return p.AC == 64 ? cx_launch_analysis_m<2>(R, ana, Y, C, g, p, pp, st)
+                    : cx_launch_analysis_m<1>(R, ana, Y, C, g, p, pp, st);
+}
+
+}  // namespace vtc

@@ -72,8 +72,9 @@ SIGNATURES = {
     'vtc_conv_code_dims': (_i32, [_GEOM_P, ctypes.POINTER(ctypes.c_int32),
                                   ctypes.POINTER(ctypes.c_int32)]),
     'vtc_conv_ista_fista_workspace_bytes': (_sz, [_GEOM_P]),
+    'vtc_conv_x3_supported': (_i32, [_GEOM_P]),
     'vtc_conv_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _f32, _f32,
-                                   _i32, _i32, _i32, _f32, _vp, _sz,
+                                   _i32, _i32, _i32, _f32, _i32, _vp, _sz,
                                    ctypes.POINTER(_i32), _vp]),
     'vtc_fc_dict_gradient_workspace_bytes': (_sz, [_i64, _i64, _i64]),
     'vtc_fc_dict_gradient': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp,
@@ -114,7 +115,7 @@ def load_library():
     fn = getattr(lib, name)   # AttributeError if the export is missing
     fn.restype = restype
     fn.argtypes = argtypes
-  if lib.vtc_abi_version() != 1:
+  if lib.vtc_abi_version() != 2:
     raise ImportError('libvtc_hip.so ABI version mismatch')
   _lib = lib
   return lib
