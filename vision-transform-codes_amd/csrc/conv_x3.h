@@ -166,96 +166,138 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   const unsigned map4 = (unsigned)(map * 4);
   const bool ragged = (g.s != s16);                // last K step has no atom
 
-  for (int ur = 0; ur < kCxSynRows; ++ur) {
-    const int u = y0 - (K - 1) + wave + kCxSynWaves * ur;
-    if (u < 0 || u >= g.ch) continue;              // whole wave
-#pragma unroll 1
-    for (int nb = 0; nb < 2; nb += NI) {
-      int vcol[NI];
-      unsigned voff[NI];
+  // The work of a wave is a flat sequence of batches q = ((row, column pass),
+  // 2 or 4 K steps of 16 atoms); the operand loads of batch q+1 are in flight while
+  // batch q runs on the matrix pipe (two register buffers).
+  constexpr int kBatch = (MT * NI > 6) ? 2 : 4;    // K steps per batch
+  constexpr int PASSES = 2 / NI;                   // column passes per row
+  const int nbat = (nks + kBatch - 1) / kBatch;
+  const int total = kCxSynRows * PASSES * nbat;
+
+  auto row_of = [&](int q) {
+    return y0 - (K - 1) + wave + kCxSynWaves * (q / (PASSES * nbat));
+  };
+  auto col0_of = [&](int q) {
+    return x0 - (K - 1) + 32 * NI * ((q / nbat) % PASSES);
+  };
+  auto issue = [&](int q, float (&dst)[NI][kBatch][8]) {
+    const int u = row_of(q);
+    if (u < 0 || u >= g.ch) return;                // whole wave
+    const int bt = q % nbat;
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        vcol[ni] = x0 - (K - 1) + 32 * (nb + ni) + l31;
-        const bool vok = vcol[ni] >= 0 && vcol[ni] < g.cw;
-        voff[ni] = vok ? (unsigned)(8 * half) * map4 +
-                             (unsigned)(u * g.cw + vcol[ni]) * 4u
-                       : 0x80000000u;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int v = col0_of(q) + 32 * ni + l31;
+      const bool vok = v >= 0 && v < g.cw;
+      const unsigned voff = vok ? (unsigned)(8 * half) * map4 +
+                                      (unsigned)(u * g.cw + v) * 4u
+                                : 0x80000000u;
+#pragma unroll
+      for (int kk = 0; kk < kBatch; ++kk) {
+        const int ks = bt * kBatch + kk;
+        if (ks >= nks) break;
+        const bool guard = ragged && ks + 1 == nks;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          unsigned vo = voff;
+          if (guard && ks * 16 + 8 * half + j >= g.s) vo = 0x80000000u;
+          dst[ni][kk][j] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(
+                         yrs, vo, (unsigned)(ks * 16 + j) * map4, 0));
+        }
       }
-      f32x16 acc[MT][NI];
+    }
+  };
+
+  f32x16 acc[MT][NI];
+  auto compute = [&](int q, const float (&src)[NI][kBatch][8]) {
+    const int u = row_of(q);
+    if (u < 0 || u >= g.ch) return;                // whole wave
+    const int bt = q % nbat;
+    if (bt == 0) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mt][ni][r] = 0.f;
-
-      float cur[NI][8], nxt[NI][8];
-      auto fetch = [&](int ks, float (&dst)[NI][8]) {
-        const bool guard = ragged && ks + 1 == nks;
+    }
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+    for (int kk = 0; kk < kBatch; ++kk) {
+      const int ks = bt * kBatch + kk;
+      if (ks >= nks) break;
+      cx_bf16x8 bh[NI], bl[NI];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            unsigned vo = voff[ni];
-            if (guard && ks * 16 + 8 * half + j >= g.s) vo = 0x80000000u;
-            dst[ni][j] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(
-                           yrs, vo, (unsigned)(ks * 16 + j) * map4, 0));
-          }
-      };
-      fetch(0, cur);
-      for (int ks = 0; ks < nks; ++ks) {
-        if (ks + 1 < nks) fetch(ks + 1, nxt);
-        cx_bf16x8 bh[NI], bl[NI];
+      for (int ni = 0; ni < NI; ++ni) cx_split8(src[ni][kk], bh[ni], bl[ni]);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) cx_split8(cur[ni], bh[ni], bl[ni]);
+      for (int mt = 0; mt < MT; ++mt) {
+        const int off = (32 * mt + l31) * pitch + ks * 16 + 8 * half;
+        const cx_bf16x8 ah = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
+        const cx_bf16x8 al = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int off = (32 * mt + l31) * pitch + ks * 16 + 8 * half;
-          const cx_bf16x8 ah = __builtin_bit_cast(
-              cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
-          const cx_bf16x8 al = __builtin_bit_cast(
-              cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                ah, bh[ni], acc[mt][ni], 0, 0, 0);
-            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                ah, bl[ni], acc[mt][ni], 0, 0, 0);
-            acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                al, bh[ni], acc[mt][ni], 0, 0, 0);
-          }
-        }
-        if (ks + 1 < nks) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) cur[ni][j] = nxt[ni][j];
-        }
-      }
-      // col2im into this wave's copy of the tile.  Rows without a tap hold
-      // exact zeros (zero operand rows), so only the pixel range is tested.
-      const int pyb = u - y0 + half * Dm::HROWS;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int pxb = vcol[ni] - x0;
-        float* base = mine + pyb * PW + pxb;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int idx = 16 * mt + r;               // compile time
-            if (idx >= Dm::HTAPS) continue;
-            const int dy = idx / K, dx = idx % K;
-            if ((unsigned)(pyb + dy) < (unsigned)TH &&
-                (unsigned)(pxb + dx) < (unsigned)TW)
-              __hip_atomic_fetch_add(base + dy * PW + dx, acc[mt][ni][r],
-                                     __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bh[ni], acc[mt][ni], 0, 0, 0);
+          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bl[ni], acc[mt][ni], 0, 0, 0);
+          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              al, bh[ni], acc[mt][ni], 0, 0, 0);
         }
       }
     }
+    if (bt != nbat - 1) return;
+    // col2im into this wave's copy of the tile.  Register (mt, r) of a lane
+    // holds tap (dy, dx) at code column v: it belongs to pixel column v + dx.
+    // The dx sum is formed in registers first: the register is rotated by dx
+    // lanes inside its 32-lane half (ds_bpermute), lanes >= dx keep it for
+    // their own column, lanes < dx for the column 32 further right.  That
+    // leaves 2 * HROWS LDS adds per pass instead of one per tap (LDS float
+    // atomics run at ~100 cycles per instruction).  Rows without a tap hold
+    // exact zeros (zero operand rows), so only the pixel range is tested.
+    const int pyb = u - y0 + half * Dm::HROWS;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int pxb = col0_of(q) + 32 * ni + l31 - x0;
+      float* base = mine + pyb * PW + pxb;
+#pragma unroll
+      for (int dy = 0; dy < Dm::HROWS; ++dy) {
+        float main_sum = 0.f, spill_sum = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int idx = dy * K + dx;                 // compile time
+          float rot = acc[idx / 16][ni][idx % 16];
+          if (dx != 0) {
+            const int from = ((l31 - dx) & 31) | (lane & 32);
+            rot = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(
+                           from * 4, __builtin_bit_cast(int, rot)));
+          }
+          if (l31 >= dx)
+            main_sum = add_rn(main_sum, rot);
+          else
+            spill_sum = add_rn(spill_sum, rot);
+        }
+        const bool row_ok = (unsigned)(pyb + dy) < (unsigned)TH;
+        if (row_ok && (unsigned)pxb < (unsigned)TW)
+          __hip_atomic_fetch_add(base + dy * PW, main_sum, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (row_ok && l31 < K - 1 && (unsigned)(pxb + 32) < (unsigned)TW)
+          __hip_atomic_fetch_add(base + dy * PW + 32, spill_sum,
+                                 __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  float buf0[NI][kBatch][8], buf1[NI][kBatch][8];
+  issue(0, buf0);
+  for (int q = 0; q < total; q += 2) {
+    if (q + 1 < total) issue(q + 1, buf1);
+    compute(q, buf0);
+    if (q + 2 < total) issue(q + 2, buf0);
+    if (q + 1 < total) compute(q + 1, buf1);
   }
   __syncthreads();
   for (int e = tid; e < TH * TW; e += 512) {
