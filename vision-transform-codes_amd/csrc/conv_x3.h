@@ -16,9 +16,9 @@
 //
 // Synthesis: a block owns a TH x TW tile of the residual image.  Each of its
 // 8 waves takes code rows u = y0-(K-1)+wave, +8, ..., forms Q for 64 code
-// columns and adds it into ITS OWN copy of the tile in LDS (ds_add_f32).  The
-// kernel taps are ordered over the accumulator rows so that the two half-waves
-// of one ds_add never touch the same pixel; a wave's adds are then ordered by
+// columns and adds it into ITS OWN copy of the tile in LDS.  The kernel taps
+// are ordered over the accumulator rows so that the two half-waves of one LDS
+// access never touch the same pixel; a wave's updates are then ordered by
 // program order, the 8 copies are summed in wave order, and the result is
 // bitwise reproducible.  The Y operand goes from HBM straight into MFMA
 // operand registers (a lane holds 8 atoms of one code position).
@@ -252,9 +252,10 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     // The dx sum is formed in registers first: the register is rotated by dx
     // lanes inside its 32-lane half (ds_bpermute), lanes >= dx keep it for
     // their own column, lanes < dx for the column 32 further right.  That
-    // leaves 2 * HROWS LDS adds per pass instead of one per tap (LDS float
-    // atomics run at ~100 cycles per instruction).  Rows without a tap hold
-    // exact zeros (zero operand rows), so only the pixel range is tested.
+    // leaves 2 * HROWS LDS updates per pass instead of one per tap (measured:
+    // one ds_add_f32 per tap cost 100 cycles each and 63% of the kernel).
+    // Rows without a tap hold exact zeros (zero operand rows), so only the
+    // pixel range is tested.
     const int pyb = u - y0 + half * Dm::HROWS;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -262,6 +263,18 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
       float* base = mine + pyb * PW + pxb;
 #pragma unroll
       for (int dy = 0; dy < Dm::HROWS; ++dy) {
+        // plain read-modify-write (volatile keeps the order of this wave's
+        // LDS accesses; the two lanes groups never share a pixel): the
+        // reads are issued before the shuffles that produce the addends
+        const bool row_ok = (unsigned)(pyb + dy) < (unsigned)TH;
+        const bool main_ok = row_ok && (unsigned)pxb < (unsigned)TW;
+        const bool spill_ok =
+            row_ok && l31 < K - 1 && (unsigned)(pxb + 32) < (unsigned)TW;
+        volatile float* pm = base + dy * PW;
+        volatile float* ps = base + dy * PW + 32;
+        float old_main = 0.f, old_spill = 0.f;
+        if (main_ok) old_main = *pm;
+        if (spill_ok) old_spill = *ps;
         float main_sum = 0.f, spill_sum = 0.f;
 #pragma unroll
         for (int dx = 0; dx < K; ++dx) {
@@ -278,14 +291,8 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
           else
             spill_sum = add_rn(spill_sum, rot);
         }
-        const bool row_ok = (unsigned)(pyb + dy) < (unsigned)TH;
-        if (row_ok && (unsigned)pxb < (unsigned)TW)
-          __hip_atomic_fetch_add(base + dy * PW, main_sum, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (row_ok && l31 < K - 1 && (unsigned)(pxb + 32) < (unsigned)TW)
-          __hip_atomic_fetch_add(base + dy * PW + 32, spill_sum,
-                                 __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (main_ok) *pm = add_rn(old_main, main_sum);
+        if (spill_ok) *ps = add_rn(old_spill, spill_sum);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -318,11 +325,14 @@ struct __attribute__((packed, aligned(2))) CxUnaligned16 {
   uint32_t x, y, z, w;
 };
 
-template <int MA>   // 32-atom tiles per block (atom chunk AC = 32 * MA)
+// MA: 32-atom tiles per block (atom chunk AC = 32 * MA).  FAST: the common
+// case (FISTA, soft threshold, no early stopping) with every option folded at
+// compile time; the other instantiation reads them from ProxParams.
+template <int MA, bool FAST>
 __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
-    ProxParams pp) {
+    int tiles_u, int chunks, ProxParams pp) {
   constexpr int AC = 32 * MA;
   extern __shared__ __attribute__((aligned(16))) char cx_lds[];
   char* lds = cx_lds;
@@ -336,9 +346,18 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int tile_v = blockIdx.x % tiles_v, tile_u = blockIdx.x / tiles_v;
-  const int chunk = blockIdx.y;
-  const int64_t img = blockIdx.z;
+  // Block -> tile, XCD aware.  Workgroups are dealt round-robin to the 8 XCDs
+  // (one L2 each); the tiles_v tiles of one band (8 code rows of one atom
+  // chunk) share their boundary cache lines, because code rows are not
+  // 128-byte aligned, so a band stays on one XCD: block L runs on XCD L % 8,
+  // and slots L / 8 walk the tiles of band (slot / tiles_v) * 8 + XCD.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_v = slot % tiles_v;
+  const int64_t band = (int64_t)(slot / tiles_v) * 8 + xcd;
+  if (band >= (int64_t)tiles_u * chunks * g.b) return;   // whole block
+  const int chunk = (int)(band % chunks);
+  const int tile_u = (int)((band / chunks) % tiles_u);
+  const int64_t img = band / ((int64_t)chunks * tiles_u);
   const int u0 = tile_u * kCxAnaRows, v0 = tile_v * kCxStrip;
   {
     const uint4* src = reinterpret_cast<const uint4*>(
@@ -370,6 +389,66 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const int lu = wave + 4 * pass;
     const int u = u0 + lu;
     if (u >= g.ch) continue;                       // whole wave
+    const bool fista = FAST ? true : (pp.fista != 0);
+    const bool early = FAST ? false : (pp.delta_sum != nullptr);
+    // Accumulator tile t = (atom tile t >> 1, column tile t & 1): lane l31 is
+    // the code column, register r the atom (r & 3) + 8 (r >> 2) + 4 half, so
+    // a wave access is two 128-byte row segments.  (Measured alternative:
+    // atoms on the lanes and 8- or 16-byte accesses along the row -- a quarter
+    // of the instructions but 32 cache lines per instruction -- is 45%
+    // slower.)  Buffer addressing: lane offset + a scalar offset per register;
+    // positions outside the code map get an out-of-range offset (loads give
+    // 0, stores are dropped).
+    auto tile_offset = [&](int t) -> unsigned {
+      const int v = v0 + 32 * (t & 1) + l31;
+      const int a0 = chunk * AC + 32 * (t >> 1) + 4 * half;
+      return v < g.cw ? (unsigned)a0 * map4 + (unsigned)(u * g.cw + v) * 4u
+                      : 0x80000000u;
+    };
+    auto atoms_left = [&](int t) -> int {          // rows rr < this exist
+      return ragged ? g.s - (chunk * AC + 32 * (t >> 1) + 4 * half) : 64;
+    };
+    auto load_tile = [&](int t, float (&yv)[16], float (&cv)[16]) {
+      const unsigned lane_off = tile_offset(t);
+      const int left = atoms_left(t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const unsigned vo = rr < left ? lane_off : 0x80000000u;
+        yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            yrs, vo, (unsigned)rr * map4, 0));
+        if (fista)
+          cv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+              crs, vo, (unsigned)rr * map4, 0));
+      }
+    };
+    auto finish_tile = [&](int t, const float (&yv)[16],
+                           const float (&cv)[16], const f32x16& tile) {
+      const unsigned lane_off = tile_offset(t);
+      const int left = atoms_left(t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const unsigned vo = rr < left ? lane_off : 0x80000000u;
+        const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
+        const float c = FAST ? shrink(p, pp.cutoff, VTC_SOFT)
+                             : shrink(p, pp.cutoff, pp.mode);
+        float d;
+        if (fista) {
+          d = sub_rn(c, cv[r]);
+          __builtin_amdgcn_raw_buffer_store_b32(
+              __float_as_uint(add_rn(c, mul_rn(pp.beta, d))), yrs, vo,
+              (unsigned)rr * map4, 0);
+        } else {
+          d = sub_rn(c, yv[r]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), crs, vo,
+                                              (unsigned)rr * map4, 0);
+        if (early && vo != 0x80000000u) local += (double)(fabsf(d) / pp.eta);
+      }
+    };
+    float yA[16], cA[16], yB[16], cB[16];
+    load_tile(0, yA, cA);
     f32x16 acc[MA][2];
 #pragma unroll
     for (int ma = 0; ma < MA; ++ma)
@@ -407,58 +486,23 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
         }
       }
     }
-    // gradient step, threshold, extrapolation on the accumulator tile.
+    // gradient step, threshold, extrapolation on the accumulator tiles, as
+    // a pipeline over the 2 * MA tiles: the Y / code loads of tile t+1 are
+    // issued before tile t is finished and stored (a buffer store orders
+    // later loads behind it), those of tile 0 before the matrix loop.
     // Buffer addressing: lane offset (atom a0, row u, column v) + a scalar
     // offset per register; positions outside the code map get an
     // out-of-range offset (loads give 0, stores are dropped).
-#pragma unroll
-    for (int ma = 0; ma < MA; ++ma) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int v = v0 + 32 * ni + l31;
-        const int a0 = chunk * AC + 32 * ma + 4 * half;
-        const unsigned lane_off =
-            (unsigned)a0 * map4 + (unsigned)(u * g.cw + v) * 4u;
-        const bool col_ok = v < g.cw;
-        float yv[16], cv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2);
-          const bool ok = col_ok && (!ragged || a0 + rr < g.s);
-          const unsigned vo = ok ? lane_off : 0x80000000u;
-          yv[r] = __builtin_bit_cast(
-              float, __builtin_amdgcn_raw_buffer_load_b32(
-                         yrs, vo, (unsigned)rr * map4, 0));
-          cv[r] = 0.f;
-          if (pp.fista)
-            cv[r] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(
-                           crs, vo, (unsigned)rr * map4, 0));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2);
-          const bool ok = col_ok && (!ragged || a0 + rr < g.s);
-          const unsigned vo = ok ? lane_off : 0x80000000u;
-          const float c = shrink(
-              sub_rn(yv[r], mul_rn(pp.eta, acc[ma][ni][r])), pp.cutoff,
-              pp.mode);
-          float d;
-          if (pp.fista) {
-            d = sub_rn(c, cv[r]);
-            __builtin_amdgcn_raw_buffer_store_b32(
-                __builtin_bit_cast(unsigned,
-                                   add_rn(c, mul_rn(pp.beta, d))),
-                yrs, vo, (unsigned)rr * map4, 0);
-          } else {
-            d = sub_rn(c, yv[r]);
-          }
-          __builtin_amdgcn_raw_buffer_store_b32(
-              __builtin_bit_cast(unsigned, c), crs, vo, (unsigned)rr * map4,
-              0);
-          if (pp.delta_sum && ok) local += (double)(fabsf(d) / pp.eta);
-        }
-      }
+    load_tile(1, yB, cB);
+    finish_tile(0, yA, cA, acc[0][0]);
+    if (MA == 2) {
+      load_tile(2, yA, cA);
+      finish_tile(1, yB, cB, acc[0][1]);
+      load_tile(3, yB, cB);
+      finish_tile(2, yA, cA, acc[MA - 1][0]);
+      finish_tile(3, yB, cB, acc[MA - 1][1]);
+    } else {
+      finish_tile(1, yB, cB, acc[0][1]);
     }
   }
   if (pp.delta_sum) {
@@ -557,7 +601,7 @@ static int cx_launch_synth(const float* Y, const uint16_t* syn, const float* X,
   return VTC_ERR_UNSUPPORTED;
 }
 
-template <int MA>
+template <int MA, bool FAST>
 static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 float* C, const ConvGeo& g, const CxPlan& p,
                                 const ProxParams& pp, hipStream_t st) {
@@ -566,14 +610,19 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
   static bool attr_set = false;
   if (!attr_set) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA>),
+        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA, FAST>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_analysis_x3_kernel<MA>,
-                     dim3((unsigned)(tiles_v * tiles_u), (unsigned)p.chunks,
-                          (unsigned)g.b),
-                     dim3(256), p.ana_lds, st, R, ana, Y, C, g, tiles_v, pp);
+  const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
+  const int64_t blocks = ceil_div(bands, 8) * 8 * tiles_v;
+  if (blocks > 0x7fffffffLL) {
+    set_error("conv bf16x3: too many tiles");
+    return VTC_ERR_INVALID_ARGUMENT;
+  }
+  hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST>),
+                     dim3((unsigned)blocks), dim3(256), p.ana_lds, st, R, ana,
+                     Y, C, g, tiles_v, tiles_u, p.chunks, pp);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
@@ -581,8 +630,12 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
 static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
                               float* C, const ConvGeo& g, const CxPlan& p,
                               const ProxParams& pp, hipStream_t st) {
-  return p.AC == 64 ? cx_launch_analysis_m<2>(R, ana, Y, C, g, p, pp, st)
-                    : cx_launch_analysis_m<1>(R, ana, Y, C, g, p, pp, st);
+  const bool fast = pp.fista && pp.mode == VTC_SOFT && !pp.delta_sum;
+  if (p.AC == 64)
+    return fast ? cx_launch_analysis_m<2, true>(R, ana, Y, C, g, p, pp, st)
+                : cx_launch_analysis_m<2, false>(R, ana, Y, C, g, p, pp, st);
+  return fast ? cx_launch_analysis_m<1, true>(R, ana, Y, C, g, p, pp, st)
+              : cx_launch_analysis_m<1, false>(R, ana, Y, C, g, p, pp, st);
 }
 
 }  // namespace vtc
