@@ -221,6 +221,40 @@ int vtc_code_energy(const float* codes, int64_t b, int64_t s,
 int vtc_hessian_ema(float* hessian_diagonal, const float* energy,
                     int64_t global_batch, int64_t s, void* stream);
 
+/* ---- validation metrics ---------------------
+ * Device reductions behind training/sparse_coding.py:177-229 `compute_metrics`
+ * (LASSO loss terms, normalised L0, pSNR, dictionary change); the host side
+ * (training/sparse_coding.py of this package) turns them into the reference's
+ * dictionary of scalars. */
+/* residual (b,n) = codes dictionary - images */
+int vtc_fc_residual(const float* images, const float* dictionary,
+                    const float* codes, float* residual, int64_t b, int64_t n,
+                    int64_t s, void* stream);
+/* residual (b,c,h,w) = mask * (conv_transpose2d(codes, dictionary) -
+ * images_padded); the mask zeroes the padding the reference crops away */
+int vtc_conv_residual(const float* images_padded, const float* dictionary,
+                      const float* codes, float* residual,
+                      const vtc_conv_geometry* g, void* stream);
+/* per row of x (rows, cols): sum x^2, sum |x|, count of non-zeros; any of the
+ * three outputs (rows floats each) may be NULL */
+int vtc_row_stats(const float* x, int64_t rows, int64_t cols, float* sumsq,
+                  float* l1, float* l0, void* stream);
+/* out[r] = sum over groups of ||codes[r, group]||_2 ; index/valid are the
+ * padded (G, m) group tables of vtc_group_gather_cols */
+int vtc_group_norm_sum(const float* codes, const int32_t* index,
+                       const uint8_t* valid, float* out, int64_t b, int64_t s,
+                       int64_t groups, int64_t m, void* stream);
+/* out_min_max[0..1] = min, max over the window of outer x rows x cols
+ * elements at x[o*outer_pitch + r*row_pitch + c] (pitches in elements) */
+size_t vtc_window_minmax_workspace_bytes(void);
+int vtc_window_minmax(const float* x, int64_t outer, int64_t rows,
+                      int64_t cols, int64_t outer_pitch, int64_t row_pitch,
+                      float* out_min_max, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* out[r] = mean over columns of |a[r,c] - b[r,c]| */
+int vtc_rows_mean_abs_diff(const float* a, const float* b, int64_t rows,
+                           int64_t cols, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -448,6 +448,116 @@ def make_trainer(ref):
   np.savez_compressed(GOLDEN / 'trainer.npz', **out)
 
 
+class _RecordingWriter(object):
+  """Stand-in for torch.utils.tensorboard.SummaryWriter (tensorboard is not
+  installed): keeps the scalars the reference sends, ignores the images."""
+  records = []
+
+  def __init__(self, *args, **kwargs):
+    pass
+
+  def add_scalar(self, tag, value, step):
+    _RecordingWriter.records.append((tag, float(value), int(step)))
+
+  def add_image(self, *args, **kwargs):
+    pass
+
+
+def make_metrics(ref):
+  """F7: the validation metrics the reference's own train_dictionary sends to
+  its SummaryWriter (compute_metrics closure, sparse_coding.py:177-229, via
+  :497-505) at iterations 0 and 2 -- fully-connected fista, subspace fista and
+  convolutional ista with padding."""
+  import shutil
+  import tempfile
+  tb = types.ModuleType('torch.utils.tensorboard')
+  tb.SummaryWriter = _RecordingWriter
+  sys.modules['torch.utils.tensorboard'] = tb
+  out = {}
+  tmp = pathlib.Path(tempfile.mkdtemp(dir=str(REPO / 'oracle')))
+
+  def run(tag, params, train, val, D0, batch):
+    _RecordingWriter.records = []
+    D = T(D0.copy())
+    tl = torch.utils.data.DataLoader(_ListDataset(T(train)), batch_size=batch,
+                                     shuffle=False)
+    vl = torch.utils.data.DataLoader(_ListDataset(T(val)), batch_size=batch,
+                                     shuffle=False)
+    p = dict(params)
+    p['logging_folder_fullpath'] = tmp / tag
+    ref.trainer.train_dictionary(tl, vl, D, p)
+    names = sorted(set(r[0] for r in _RecordingWriter.records))
+    steps = sorted(set(r[2] for r in _RecordingWriter.records))
+    table = np.zeros((len(steps), len(names)))
+    for name, value, step in _RecordingWriter.records:
+      table[steps.index(step), names.index(name)] = value
+    out[tag + '_names'] = np.array(names)
+    out[tag + '_steps'] = np.array(steps)
+    out[tag + '_values'] = table
+    # the restatement, same loop
+    Dm = T(D0.copy())
+    q = dict(params)
+    hist = sc_oracle.train_steps(
+        [T(train[batch * i: batch * i + batch])
+         for i in range(len(train) // batch)], Dm, q,
+        validation_batches=[T(val[batch * i: batch * i + batch])
+                            for i in range(len(val) // batch)])
+    for si, step in enumerate(steps):
+      for ni, name in enumerate(names):
+        ours = float(hist[step]['validation'][name])
+        theirs = table[si, ni]
+        print('  %-22s step %d %-40s ref %.9g  oracle %.9g  rel %.2e' % (
+            tag, step, name, theirs, ours,
+            abs(ours - theirs) / max(abs(theirs), 1e-30)))
+    report('metrics %s final dictionary' % tag, Dm, D)
+    return D.numpy().copy()
+
+  X = gaussian_patches(60, 96, 64)
+  V = gaussian_patches(61, 64, 64)
+  D0 = unit_rows(62, 128, 64)
+  fc = {
+      'mode': 'fully-connected', 'num_epochs': 1,
+      'code_inference_algorithm': 'fista',
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.02, 'num_iters': 15}},
+      'dictionary_update_algorithm': 'sc_steepest_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.1, 'num_iters': 1}},
+      'training_visualization_schedule': set([0, 2]),
+      'reshaped_kernel_size': (8, 8)}
+  out['fc_images'], out['fc_validation'], out['fc_dictionary0'] = X, V, D0
+  out['fc_dictionary_final'] = run('fc', fc, X, V, D0, 32)
+  groups = [list(range(4 * g, 4 * g + 4)) for g in range(32)]
+  sub = dict(fc)
+  sub.update({'code_inference_algorithm': 'subspace_fista',
+              'dictionary_update_algorithm':
+                  'subspace_sc_cheap_quadratic_descent',
+              'group_assignments': groups,
+              'subspace_alignment_penalty': 2e-4})
+  out['sub_dictionary_final'] = run('sub', sub, X, V, D0, 32)
+  lead, trail = sc_oracle.conv_padding_amount(16, 8, 4)
+  padded = 16 + lead + trail
+  rs = np.random.RandomState(63)
+  imgs = np.zeros((10, 1, padded, padded), np.float32)
+  imgs[:, :, lead:lead + 16, lead:lead + 16] = (
+      0.5 * rs.randn(10, 1, 16, 16)).astype(np.float32)
+  K0 = unit_kernels(64, 6, 1, 8, 8)
+  conv = {
+      'mode': 'convolutional', 'num_epochs': 1,
+      'code_inference_algorithm': 'ista',
+      'strides': (4, 4), 'padding': ((lead, trail), (lead, trail)),
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.05, 'num_iters': 8}},
+      'dictionary_update_algorithm': 'sc_steepest_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.005, 'num_iters': 1}},
+      'training_visualization_schedule': set([0, 2])}
+  out['conv_images_padded'], out['conv_validation'] = imgs[:6], imgs[6:]
+  out['conv_dictionary0'] = K0
+  out['conv_padding'] = np.array(conv['padding'])
+  out['conv_dictionary_final'] = run('conv', conv, imgs[:6], imgs[6:], K0, 2)
+  shutil.rmtree(str(tmp), ignore_errors=True)
+  np.savez_compressed(GOLDEN / 'metrics.npz', **out)
+
+
 def make_whitened(ref):
   """F6: 'realistic' patches.  Synthetic 1/f images -> the reference's own
   whiten_center_surround (vtc/utils/image_processing.py:267-308, parameters
@@ -488,7 +598,8 @@ def make_whitened(ref):
 
 MAKERS = {'fc_c1': make_fc_c1, 'fc_c2_mini': make_fc_c2_mini,
           'subspace': make_subspace, 'conv': make_conv,
-          'trainer': make_trainer, 'whitened': make_whitened}
+          'trainer': make_trainer, 'whitened': make_whitened,
+          'metrics': make_metrics}
 
 
 def main(argv):

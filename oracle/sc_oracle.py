@@ -25,6 +25,8 @@ kernels can be scored.
 """
 import math
 
+import numpy as np
+
 import torch
 
 
@@ -537,10 +539,62 @@ def hessian_diag_ema_(hessian_diagonal, codes):
   return hessian_diagonal
 
 
-def train_steps(batches, dictionary, params):
+def compute_metrics(batch_images, batch_codes, dictionary,
+                    previous_dictionary, sparsity_weight, params):
+  """Restates the `compute_metrics` closure of
+  vtc/training/sparse_coding.py:177-229 (numpy on the host, as there)."""
+  mode = params['mode']
+  inf_alg = params['code_inference_algorithm']
+  metrics = {}
+  images_np = batch_images.numpy()
+  if mode == 'fully-connected':
+    recons = torch.mm(batch_codes, dictionary).numpy()
+    axes = 1
+  else:
+    recons = torch.nn.functional.conv_transpose2d(
+        batch_codes, dictionary, stride=params['strides']).numpy()
+    pad = params['padding']
+    if pad is not None:                                        # :188-194
+      recons = recons[:, :, pad[0][0]:-pad[0][1], pad[1][0]:-pad[1][1]]
+      images_np = images_np[:, :, pad[0][0]:-pad[0][1], pad[1][0]:-pad[1][1]]
+    axes = (1, 2, 3)
+  metrics['Average LASSO L2 component'] = np.mean(
+      0.5 * np.sum(np.square(recons - images_np), axis=axes))
+  if inf_alg in ('subspace_ista', 'subspace_fista'):           # :199-206
+    groups = params['group_assignments']
+    sum_of_group_norms = np.zeros((len(batch_codes),))
+    for g in groups:
+      sum_of_group_norms += torch.norm(batch_codes[:, g], p=2, dim=1).numpy()
+    metrics['Average LASSO lagrange component'] = np.mean(
+        sparsity_weight * sum_of_group_norms)
+  else:
+    metrics['Average LASSO lagrange component'] = np.mean(
+        sparsity_weight * torch.norm(batch_codes, p=1, dim=axes).numpy())
+  metrics['Average LASSO Loss'] = (
+      metrics['Average LASSO L2 component'] +
+      metrics['Average LASSO lagrange component'])
+  metrics['Average Normalized L0'] = float(torch.mean(
+      torch.norm(batch_codes, p=0, dim=axes) /
+      np.prod(batch_codes.shape[1:])).numpy())
+  sig_mag = np.max(images_np) - np.min(images_np)              # :218
+  psnrs = []
+  for i in range(recons.shape[0]):                             # plotting.py:35-39
+    mse = np.mean(np.square(images_np[i] - recons[i]))
+    if mse != 0:
+      psnrs.append(10. * np.log10((sig_mag ** 2) / mse))
+  metrics['Average pSNR of reconstructions'] = np.mean(psnrs)
+  metrics['Average change in dictionary kernels'] = torch.mean(
+      torch.abs(dictionary - previous_dictionary), dim=axes).numpy()
+  return metrics
+
+
+def train_steps(batches, dictionary, params, validation_batches=None):
   """Runs the per-batch step of vtc/training/sparse_coding.py:444-517 over a
   list of batches, mutating `dictionary` in place.  Returns a list with one
-  dict per step: {'codes', 'dictionary' (copy after the update), 'hessian'}.
+  dict per step: {'codes', 'dictionary' (copy after the update), 'hessian',
+  'validation'}.  'validation' is the mean of compute_metrics over
+  `validation_batches` taken BEFORE the step, at the iterations listed in
+  params['training_visualization_schedule'] (:497-505), else None.
 
   params: mode, code_inference_algorithm, inference_param_schedule,
   dictionary_update_algorithm, dict_update_param_schedule and the optional
@@ -558,6 +612,26 @@ def train_steps(batches, dictionary, params):
                              'subspace_sc_cheap_quadratic_descent')
   hessian = dictionary.new_zeros(dictionary.shape[0]) if uses_hessian else None
   history = []
+  vis_sched = params.get('training_visualization_schedule')
+  previous_dictionary = dictionary.clone()
+
+  def infer(batch):
+    # ---- inference (vtc/training/sparse_coding.py:124-140)
+    if inf_alg in ('subspace_ista', 'subspace_fista'):
+      return subspace_ista_fista(
+          batch, dictionary, groups, lam, inf_iters, variant=inf_alg[9:],
+          hard_threshold=params.get('hard_threshold', False))
+    if mode == 'fully-connected':
+      return fc_ista_fista(
+          batch, dictionary, lam, inf_iters, variant=inf_alg,
+          nonnegative_only=params.get('nonnegative_only', False),
+          hard_threshold=params.get('hard_threshold', False))
+    return conv_ista_fista(
+        batch, dictionary, params['strides'], params['padding'], lam,
+        inf_iters, variant=inf_alg,
+        nonnegative_only=params.get('nonnegative_only', False),
+        hard_threshold=params.get('hard_threshold', False))
+
   for step_idx, batch in enumerate(batches):
     if step_idx in inf_sched:
       lam = inf_sched[step_idx]['sparsity_weight']
@@ -565,22 +639,15 @@ def train_steps(batches, dictionary, params):
     if step_idx in upd_sched:
       upd_step = upd_sched[step_idx]['stepsize']
       upd_iters = upd_sched[step_idx]['num_iters']
-    # ---- inference (vtc/training/sparse_coding.py:124-140)
-    if inf_alg in ('subspace_ista', 'subspace_fista'):
-      codes = subspace_ista_fista(
-          batch, dictionary, groups, lam, inf_iters, variant=inf_alg[9:],
-          hard_threshold=params.get('hard_threshold', False))
-    elif mode == 'fully-connected':
-      codes = fc_ista_fista(
-          batch, dictionary, lam, inf_iters, variant=inf_alg,
-          nonnegative_only=params.get('nonnegative_only', False),
-          hard_threshold=params.get('hard_threshold', False))
-    else:
-      codes = conv_ista_fista(
-          batch, dictionary, params['strides'], params['padding'], lam,
-          inf_iters, variant=inf_alg,
-          nonnegative_only=params.get('nonnegative_only', False),
-          hard_threshold=params.get('hard_threshold', False))
+    validation = None
+    if vis_sched is not None and step_idx in vis_sched:
+      per_batch = [compute_metrics(v, infer(v), dictionary,
+                                   previous_dictionary, lam, params)
+                   for v in validation_batches]
+      validation = {x: np.mean([m[x] for m in per_batch])
+                    for x in per_batch[0]}
+    codes = infer(batch)
+    previous_dictionary.copy_(dictionary)                      # :514
     # ---- dictionary update (vtc/training/sparse_coding.py:142-168)
     if uses_hessian:
       hessian_diag_ema_(hessian, codes)
@@ -607,5 +674,6 @@ def train_steps(batches, dictionary, params):
       else:
         raise KeyError('Unrecognized dict update algorithm: ' + upd_alg)
     history.append({'codes': codes, 'dictionary': dictionary.clone(),
-                    'hessian': None if hessian is None else hessian.clone()})
+                    'hessian': None if hessian is None else hessian.clone(),
+                    'validation': validation})
   return history

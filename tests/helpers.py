@@ -61,3 +61,39 @@ def assert_codes_match(ours, ref, rel_tol, what, max_flip_mag=NEAR_THRESHOLD):
 
 def to_dev(a, device):
   return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def metrics_cases(g):
+  """The three training runs behind tests/golden/metrics.npz
+  (oracle/make_golden.py make_metrics): tag -> (params, train, validation,
+  initial dictionary, batch size)."""
+  fc = {
+      'mode': 'fully-connected', 'num_epochs': 1,
+      'code_inference_algorithm': 'fista',
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.02, 'num_iters': 15}},
+      'dictionary_update_algorithm': 'sc_steepest_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.1, 'num_iters': 1}},
+      'training_visualization_schedule': set([0, 2])}
+  sub = dict(fc)
+  sub.update({'code_inference_algorithm': 'subspace_fista',
+              'dictionary_update_algorithm':
+                  'subspace_sc_cheap_quadratic_descent',
+              'group_assignments': [list(range(4 * k, 4 * k + 4))
+                                    for k in range(32)],
+              'subspace_alignment_penalty': 2e-4})
+  pad = tuple(tuple(int(v) for v in row) for row in g['conv_padding'])
+  conv = {
+      'mode': 'convolutional', 'num_epochs': 1,
+      'code_inference_algorithm': 'ista', 'strides': (4, 4), 'padding': pad,
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.05, 'num_iters': 8}},
+      'dictionary_update_algorithm': 'sc_steepest_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.005, 'num_iters': 1}},
+      'training_visualization_schedule': set([0, 2])}
+  return {
+      'fc': (fc, g['fc_images'], g['fc_validation'], g['fc_dictionary0'], 32),
+      'sub': (sub, g['fc_images'], g['fc_validation'], g['fc_dictionary0'],
+              32),
+      'conv': (conv, g['conv_images_padded'], g['conv_validation'],
+               g['conv_dictionary0'], 2)}

@@ -82,7 +82,7 @@ def test_trainer_rejects_out_of_scope_features_and_bad_names():
                                              'num_iters': 1}}}
   with pytest.raises(NotImplementedError):
     sparse_coding.train_dictionary(
-        [], [], D, dict(base, training_visualization_schedule={0}))
+        [], [], D, dict(base, dict_element_rp_schedule={0: {}}))
   with pytest.raises(AssertionError):
     sparse_coding.train_dictionary(
         [], [], D, dict(base, inference_param_schedule={1: {}}))

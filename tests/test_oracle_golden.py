@@ -211,6 +211,29 @@ def test_trainer_trajectories():
                            g['conv_dict_after_step%d' % (i + 1)]) < 2e-6
 
 
+def test_validation_metrics():
+  """compute_metrics restatement against the scalars the reference's own
+  train_dictionary sent to its SummaryWriter (sparse_coding.py:177-229,
+  :497-505): fully-connected, subspace and convolutional."""
+  g = helpers.load('metrics')
+  for tag, (params, train, val, D0, batch) in helpers.metrics_cases(g).items():
+    D = T(D0.copy())
+    hist = sc_oracle.train_steps(
+        [T(train[batch * i: batch * i + batch])
+         for i in range(len(train) // batch)], D, params,
+        validation_batches=[T(val[batch * i: batch * i + batch])
+                            for i in range(len(val) // batch)])
+    names = [str(x) for x in g[tag + '_names']]
+    for si, step in enumerate(g[tag + '_steps']):
+      got = hist[int(step)]['validation']
+      for ni, name in enumerate(names):
+        want = g[tag + '_values'][si, ni]
+        assert abs(float(got[name]) - want) <= 1e-6 * max(abs(want), 1e-12), (
+            tag, int(step), name, float(got[name]), want)
+    assert hist[1]['validation'] is None
+    assert helpers.rel_err(D.numpy(), g[tag + '_dictionary_final']) < 2e-6
+
+
 def test_whitened_patches():
   g = helpers.load('whitened')
   X = T(g['images'])

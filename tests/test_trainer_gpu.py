@@ -68,6 +68,32 @@ def test_conv_trajectory(device):
                            g['conv_dict_after_step%d' % steps]) < 2e-5
 
 
+@pytest.mark.parametrize('tag', ['fc', 'sub', 'conv'])
+def test_validation_metrics(device, tag):
+  """training_visualization_schedule: the validation metrics (device
+  reductions of vtc_hip) against the scalars the reference's train_dictionary
+  sent to TensorBoard.  Tolerance 2e-5 relative (float32 sums in a different
+  order; pSNR is a log of them)."""
+  from training import sparse_coding
+  g = helpers.load('metrics')
+  params, train, val, D0, batch = helpers.metrics_cases(g)[tag]
+  D = helpers.to_dev(D0.copy(), device)
+  X, V = helpers.to_dev(train, device), helpers.to_dev(val, device)
+  tb = [X[batch * i: batch * i + batch] for i in range(len(train) // batch)]
+  vb = [V[batch * i: batch * i + batch] for i in range(len(val) // batch)]
+  state = sparse_coding.train_dictionary(tb, vb, D, params)
+  names = [str(x) for x in g[tag + '_names']]
+  assert [it for it, _ in state.metrics_log] == [int(x)
+                                                 for x in g[tag + '_steps']]
+  for si, (_, got) in enumerate(state.metrics_log):
+    assert sorted(got) == names
+    for ni, name in enumerate(names):
+      want = g[tag + '_values'][si, ni]
+      assert abs(float(got[name]) - want) <= 2e-5 * max(abs(want), 1e-12), (
+          tag, si, name, float(got[name]), want)
+  assert helpers.rel_err(D.cpu().numpy(), g[tag + '_dictionary_final']) < 2e-5
+
+
 def test_subspace_step_runs_and_keeps_unit_norm(device):
   from training import sparse_coding
   X = helpers.to_dev(helpers.gaussian_patches(80, 64, 64), device)

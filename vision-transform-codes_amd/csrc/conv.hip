@@ -618,6 +618,23 @@ extern "C" int vtc_conv_ista_fista(
   return VTC_OK;
 }
 
+// residual = mask * (conv_transpose2d(codes, D) - images_padded): the masked
+// reconstruction error (the trainer's validation metrics crop the padding,
+// training/sparse_coding.py:185-195, which is what the mask zeroes).
+extern "C" int vtc_conv_residual(const float* images_padded,
+                                 const float* dictionary, const float* codes,
+                                 float* residual,
+                                 const vtc_conv_geometry* geom, void* stream) {
+  VTC_REQUIRE(images_padded && dictionary && codes && residual,
+              "vtc_conv_residual: null pointer");
+  ConvGeo g;
+  int rc = make_geo(geom, &g);
+  if (rc != VTC_OK) return rc;
+  if (g.b == 0) return VTC_OK;
+  return launch_synthesis(codes, dictionary, images_padded, residual, g,
+                          as_stream(stream));
+}
+
 extern "C" size_t vtc_conv_dict_gradient_workspace_bytes(
     const vtc_conv_geometry* geom) {
   ConvGeo g;

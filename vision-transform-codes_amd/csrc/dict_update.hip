@@ -305,6 +305,20 @@ extern "C" int vtc_fc_dict_gradient(const float* images,
   return launch_slab_reduce(slabs, slices, s * n, grad_sum, st);
 }
 
+// E = codes * dictionary - images  (the reconstruction residual; the trainer's
+// validation metrics, training/sparse_coding.py:181-203)
+extern "C" int vtc_fc_residual(const float* images, const float* dictionary,
+                               const float* codes, float* residual, int64_t b,
+                               int64_t n, int64_t s, void* stream) {
+  VTC_REQUIRE((images && dictionary && codes && residual) || b == 0,
+              "vtc_fc_residual: null pointer");
+  VTC_REQUIRE(b >= 0 && n > 0 && s > 0, "vtc_fc_residual: bad sizes");
+  if (b == 0) return VTC_OK;
+  EpiMinus e{residual, images, n, n};
+  return launch_gemm_f32<true, false>(codes, s, dictionary, n, b, n, s, 1, e,
+                                      as_stream(stream));
+}
+
 extern "C" size_t vtc_subspace_alignment_gradient_workspace_bytes(
     int64_t slots, int64_t n) {
   return align_up((size_t)(slots > 0 ? slots : 1) * n * sizeof(float), 256);

@@ -5,18 +5,22 @@ Mirrors the calling convention of vision_transform_codes/training/
 sparse_coding.py (train_dictionary at :9-10, parameter dictionary at :52-117)
 for the part of it that is on the hot path: schedule lookup, code inference,
 Hessian-diagonal EMA, dictionary update (:124-168, :444-517), plus dictionary
-checkpoints (:170-175).  TensorBoard visualisation and the interactive
-reset/prune machinery are host-side bookkeeping outside this engine's scope
-and raise NotImplementedError if requested.
+checkpoints (:170-175) and the validation metrics (:177-229, :497-505) as
+device reductions.  TensorBoard image summaries and the interactive reset/prune
+machinery are host-side bookkeeping outside this engine's scope: the former are
+skipped (the metrics are kept in TrainingStep.metrics_log instead of a
+SummaryWriter), the latter raises NotImplementedError if requested.
 
 Data parallelism (not in the reference): when vtc_hip.parallel is enabled each
 rank feeds its own shard of every batch; inference is local, the dictionary
 gradient and the code energy are summed over ranks with one RCCL all-reduce
 each, and all ranks apply the same update.
 """
+import ctypes
 import pickle
 import time
 
+import numpy as np
 import torch
 
 import vtc_hip
@@ -115,6 +119,10 @@ class TrainingStep(object):
     self.inf_num_iters = None
     self.upd_stepsize = None
     self.upd_num_iters = None
+    # dictionary before the latest update (:514) and the validation metrics
+    # recorded at the iterations of 'training_visualization_schedule'
+    self.previous_dictionary = dictionary.clone()
+    self.metrics_log = []
 
   def infer_codes(self, batch_images):
     """Keyword call into the inference plugin (sparse_coding.py:124-140)."""
@@ -184,6 +192,100 @@ class TrainingStep(object):
     self.update_dictionary(batch_images, codes)
     return codes
 
+  def compute_metrics(self, batch_images, batch_codes):
+    """The validation metrics of sparse_coding.py:177-229, same keys.  The
+    residual, its per-sample energy, the l1 / l0 / group norms of the codes,
+    the signal range and the dictionary change are HIP reductions; only
+    b + s floats come back to the host, where the means and the pSNR
+    logarithm are taken in numpy as in the reference."""
+    lib = vtc_hip.load_library()
+    images = vtc_hip.require_device_tensor(
+        batch_images, 'batch_images').contiguous()
+    codes = vtc_hip.require_device_tensor(
+        batch_codes, 'batch_codes').contiguous()
+    D = self.dictionary.contiguous()
+    device = images.device
+    stream = vtc_hip.current_stream(device)
+    b = images.shape[0]
+    residual = torch.empty_like(images)
+    minmax = torch.empty(2, dtype=torch.float32, device=device)
+    mm_ws = vtc_hip.workspace(lib.vtc_window_minmax_workspace_bytes(), device)
+    if self.mode == 'fully-connected':
+      n, s = images.shape[1], D.shape[0]
+      vtc_hip.check(lib.vtc_fc_residual(
+          vtc_hip.ptr(images), vtc_hip.ptr(D), vtc_hip.ptr(codes),
+          vtc_hip.ptr(residual), b, n, s, stream), 'vtc_fc_residual')
+      pixels = n
+      vtc_hip.check(lib.vtc_window_minmax(
+          vtc_hip.ptr(images), 1, b, n, 0, n, vtc_hip.ptr(minmax),
+          vtc_hip.ptr(mm_ws), mm_ws.numel(), stream), 'vtc_window_minmax')
+    else:
+      from utils import convolutions
+      geom = convolutions.geometry(images, D, self.strides, self.padding)
+      vtc_hip.check(lib.vtc_conv_residual(
+          vtc_hip.ptr(images), vtc_hip.ptr(D), vtc_hip.ptr(codes),
+          vtc_hip.ptr(residual), ctypes.byref(geom), stream),
+          'vtc_conv_residual')
+      c, h, w = images.shape[1:]
+      (lv, tv), (lh, th) = self.padding if self.padding is not None else (
+          (0, 0), (0, 0))
+      # the reference crops `lead:-trail` (:188-194); the mask of the residual
+      # zeroes the same frame
+      ih, iw = h - lv - tv, w - lh - th
+      pixels = c * ih * iw
+      first = images.reshape(-1)[lv * w + lh:]
+      vtc_hip.check(lib.vtc_window_minmax(
+          vtc_hip.ptr(first), b * c, ih, iw, h * w, w, vtc_hip.ptr(minmax),
+          vtc_hip.ptr(mm_ws), mm_ws.numel(), stream), 'vtc_window_minmax')
+    per_sample = residual.reshape(b, -1).shape[1]
+    code_len = codes.reshape(b, -1).shape[1]
+    sq_err = torch.empty(b, dtype=torch.float32, device=device)
+    l1 = torch.empty(b, dtype=torch.float32, device=device)
+    l0 = torch.empty(b, dtype=torch.float32, device=device)
+    vtc_hip.check(lib.vtc_row_stats(
+        vtc_hip.ptr(residual), b, per_sample, vtc_hip.ptr(sq_err),
+        vtc_hip.ptr(None), vtc_hip.ptr(None),
+        stream), 'vtc_row_stats')
+    vtc_hip.check(lib.vtc_row_stats(
+        vtc_hip.ptr(codes), b, code_len, vtc_hip.ptr(None), vtc_hip.ptr(l1),
+        vtc_hip.ptr(l0), stream), 'vtc_row_stats')
+    if self.inf_name in ('subspace_ista', 'subspace_fista'):
+      from vtc_hip import groups as group_tables
+      tables = group_tables.tables_for(self.groups, D.shape[0], device)
+      lagrange_rows = torch.empty(b, dtype=torch.float32, device=device)
+      vtc_hip.check(lib.vtc_group_norm_sum(
+          vtc_hip.ptr(codes), vtc_hip.ptr(tables.index),
+          vtc_hip.ptr(tables.valid), vtc_hip.ptr(lagrange_rows), b,
+          D.shape[0], tables.num_groups, tables.m, stream),
+          'vtc_group_norm_sum')
+    else:
+      lagrange_rows = l1
+    flatD = D.reshape(D.shape[0], -1)
+    change = torch.empty(D.shape[0], dtype=torch.float32, device=device)
+    vtc_hip.check(lib.vtc_rows_mean_abs_diff(
+        vtc_hip.ptr(flatD), vtc_hip.ptr(self.previous_dictionary.contiguous()),
+        flatD.shape[0], flatD.shape[1], vtc_hip.ptr(change), stream),
+        'vtc_rows_mean_abs_diff')
+
+    sq_err = sq_err.cpu().numpy()
+    lo, hi = minmax.cpu().numpy()
+    metrics = {}
+    metrics['Average LASSO L2 component'] = np.mean(0.5 * sq_err)
+    metrics['Average LASSO lagrange component'] = np.mean(
+        np.float32(self.sparsity_weight) * lagrange_rows.cpu().numpy())
+    metrics['Average LASSO Loss'] = (
+        metrics['Average LASSO L2 component'] +
+        metrics['Average LASSO lagrange component'])
+    metrics['Average Normalized L0'] = float(
+        np.mean(l0.cpu().numpy() / np.float32(code_len)))
+    sig_mag = hi - lo
+    mse = sq_err / np.float32(pixels)
+    nonzero = mse != 0
+    metrics['Average pSNR of reconstructions'] = np.mean(
+        10. * np.log10((sig_mag ** 2) / mse[nonzero]))
+    metrics['Average change in dictionary kernels'] = change.cpu().numpy()
+    return metrics
+
 
 def train_dictionary(training_image_dataset, validation_image_dataset,
                      init_dictionary, all_params):
@@ -204,12 +306,11 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
   """
   assert 0 in all_params['inference_param_schedule']
   assert 0 in all_params['dict_update_param_schedule']
-  for unsupported in ('training_visualization_schedule',
-                      'dict_element_rp_schedule'):
-    if unsupported in all_params:
-      raise NotImplementedError(
-          unsupported + ' is host-side bookkeeping outside the scope of the '
-          'MI355X engine (SURVEY.md section 8f)')
+  if 'dict_element_rp_schedule' in all_params:
+    raise NotImplementedError(
+        'dict_element_rp_schedule is host-side bookkeeping outside the scope '
+        'of the MI355X engine (SURVEY.md section 8f)')
+  vis_schedule = all_params.get('training_visualization_schedule')
   inf_schedule = all_params['inference_param_schedule']
   upd_schedule = all_params['dict_update_param_schedule']
   vtc_hip.require_device_tensor(init_dictionary, 'init_dictionary')
@@ -228,8 +329,7 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
   print_interval = all_params.get('stdout_print_interval', 1000)
 
   step = TrainingStep(init_dictionary, all_params)
-  previous_dictionary = torch.zeros_like(init_dictionary)
-  previous_dictionary.copy_(init_dictionary)
+  previous_dictionary = step.previous_dictionary
 
   start = time.time()
   total_iter_idx = 0
@@ -251,6 +351,19 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
         with open(logging_path / ('checkpoint_dictionary_iter_' +
                                   str(total_iter_idx)), 'wb') as f:
           pickle.dump(init_dictionary.cpu().numpy(), f)
+      if vis_schedule is not None and total_iter_idx in vis_schedule:
+        # validation pass (:497-505): mean of every metric over the batches of
+        # the validation set; kept in step.metrics_log (iteration, dict)
+        # instead of a TensorBoard writer, dictionary images are not drawn
+        val_metrics = []
+        for v_batch_images in validation_image_dataset:
+          if init_dictionary.device != v_batch_images.device:
+            v_batch_images = v_batch_images.to(init_dictionary.device)
+          v_codes = step.infer_codes(v_batch_images)
+          val_metrics.append(step.compute_metrics(v_batch_images, v_codes))
+        step.metrics_log.append((total_iter_idx, {
+            x: np.mean([val_metrics[y][x] for y in range(len(val_metrics))])
+            for x in val_metrics[0]}))
       if init_dictionary.device != batch_images.device:
         batch_images = batch_images.to(init_dictionary.device)
       previous_dictionary.copy_(init_dictionary)

@@ -73,6 +73,15 @@ SIGNATURES = {
                                   ctypes.POINTER(ctypes.c_int32)]),
     'vtc_conv_ista_fista_workspace_bytes': (_sz, [_GEOM_P]),
     'vtc_conv_x3_supported': (_i32, [_GEOM_P]),
+    'vtc_fc_residual': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'vtc_conv_residual': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _vp]),
+    'vtc_row_stats': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'vtc_group_norm_sum': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                  _vp]),
+    'vtc_window_minmax_workspace_bytes': (_sz, []),
+    'vtc_window_minmax': (_i32, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
+                                 _sz, _vp]),
+    'vtc_rows_mean_abs_diff': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     'vtc_conv_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _f32, _f32,
                                    _i32, _i32, _i32, _f32, _i32, _vp, _sz,
                                    ctypes.POINTER(_i32), _vp]),
