@@ -255,6 +255,28 @@ int vtc_window_minmax(const float* x, int64_t outer, int64_t rows,
 int vtc_rows_mean_abs_diff(const float* a, const float* b, int64_t rows,
                            int64_t cols, float* out, void* stream);
 
+/* ---- patch pipeline --------------------------
+ * utils/image_processing.py:267-308 whiten_center_surround (float64 FFT
+ * filtering as at :63-92, through hipFFT opened at first use) and the 'patch'
+ * operation of utils/dataset_generation.py:184-222.  Images are channel-last
+ * (count, h, w, c) float32 as in the reference. */
+size_t vtc_whiten_center_surround_workspace_bytes(int64_t count, int32_t h,
+                                                  int32_t w, int32_t c);
+/* norm_and_threshold must be 0 (the dataset pipeline's setting); 1 returns
+ * VTC_ERR_UNSUPPORTED */
+int vtc_whiten_center_surround(const float* images, float* out, int64_t count,
+                               int32_t h, int32_t w, int32_t c,
+                               float cutoff_low, float cutoff_high,
+                               int norm_and_threshold, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* patches (num, ph*pw*c): patch p = images[img_index[p],
+ * vert[p]:vert[p]+ph, horz[p]:horz[p]+pw, :] flattened; positions come from
+ * the caller's random number generator (int32 device arrays) */
+int vtc_extract_patches(const float* images, const int32_t* img_index,
+                        const int32_t* vert, const int32_t* horz,
+                        float* patches, int64_t num, int32_t h, int32_t w,
+                        int32_t c, int32_t ph, int32_t pw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,12 @@ SIGNATURES = {
     'vtc_window_minmax': (_i32, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp,
                                  _sz, _vp]),
     'vtc_rows_mean_abs_diff': (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    'vtc_whiten_center_surround_workspace_bytes': (_sz, [_i64, _i32, _i32,
+                                                         _i32]),
+    'vtc_whiten_center_surround': (_i32, [_vp, _vp, _i64, _i32, _i32, _i32,
+                                          _f32, _f32, _i32, _vp, _sz, _vp]),
+    'vtc_extract_patches': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                   _i32, _i32, _i32, _vp]),
     'vtc_conv_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _f32, _f32,
                                    _i32, _i32, _i32, _f32, _i32, _vp, _sz,
                                    ctypes.POINTER(_i32), _vp]),
