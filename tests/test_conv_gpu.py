@@ -252,3 +252,30 @@ def test_bf16x3_unsupported_geometry(device, plugins):
                                   (4, 4), None, 0.05, 2)
   helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
                              'auto fallback', max_flip_mag=1e-5)
+
+
+def test_full_size_properties(device, plugins):
+  """BASELINE configs[4] geometry (128 kernels 11x11, 256x256 images padded to
+  276x276; too slow for the oracle): (i) images are independent -- a batch of
+  two gives bit-identical codes to the two single-image runs; (ii) the run is
+  bitwise reproducible; (iii) the bf16x3 matrix-core path agrees with the
+  direct f32 kernels (5e-5 relative, support identical above 5e-6) in the
+  convergent regime."""
+  conv = plugins[0]
+  imgs, D, padding = _conv_case(4242, 11, 128, 256, 256, b=2, scale=0.1)
+  X, Dd = helpers.to_dev(imgs, device), helpers.to_dev(D, device)
+  step = 0.9 / 128
+  both = conv.run(X, Dd, (1, 1), padding, 0.05, 12, stepsize=step,
+                  precision='bf16x3')
+  again = conv.run(X, Dd, (1, 1), padding, 0.05, 12, stepsize=step,
+                   precision='bf16x3')
+  assert torch.equal(both, again)
+  for i in range(2):
+    one = conv.run(X[i:i + 1].contiguous(), Dd, (1, 1), padding, 0.05, 12,
+                   stepsize=step, precision='bf16x3')
+    assert torch.equal(one[0], both[i])
+  exact = conv.run(X[:1].contiguous(), Dd, (1, 1), padding, 0.05, 12,
+                   stepsize=step, precision='f32')
+  helpers.assert_codes_match(both[:1].cpu().numpy(), exact.cpu().numpy(),
+                             5e-5, 'conv bf16x3 vs f32 path',
+                             max_flip_mag=5e-6)

@@ -172,3 +172,32 @@ def test_group_sizes_against_oracle(device, plugins, m, precision):
                 0.03, 25, precision=precision)
   helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
                              'groups of %d' % m, max_flip_mag=1e-5)
+
+
+def test_full_size_properties(device, plugins):
+  """BASELINE configs[3] (4096 atoms in 512 groups of 8, b = 8192; too big
+  for the oracle): rows are independent (a slice of the batch reproduces the
+  same rows), the run is reproducible, and the bf16x3 path (prox
+  fused into the product epilogue, split-K residual) agrees with the exact-f32
+  kernels on a slice."""
+  sub = plugins[0]
+  b, s_atoms, n = 8192, 4096, 256
+  X = helpers.to_dev(helpers.gaussian_patches(31, b, n), device)
+  D = helpers.to_dev(helpers.unit_rows(32, s_atoms, n), device)
+  groups = [list(map(int, x)) for x in np.array_split(np.arange(s_atoms), 512)]
+  eta = 0.05
+  full = sub.run(X, D, groups, 0.008, 30, precision='bf16x3', stepsize=eta)
+  again = sub.run(X, D, groups, 0.008, 30, precision='bf16x3', stepsize=eta)
+  assert torch.equal(full, again)
+  part = sub.run(X[1024:1024 + 256].contiguous(), D, groups, 0.008, 30,
+                 precision='bf16x3', stepsize=eta)
+  # not bitwise: the residual product splits its K axis by the batch size,
+  # so the f32 summation order differs between the two runs
+  helpers.assert_codes_match(part.cpu().numpy(),
+                             full[1024:1024 + 256].cpu().numpy(), 5e-6,
+                             'slice vs full batch', max_flip_mag=1e-6)
+  exact = sub.run(X[:512].contiguous(), D, groups, 0.008, 30, precision='f32',
+                  stepsize=eta)
+  helpers.assert_codes_match(full[:512].cpu().numpy(), exact.cpu().numpy(),
+                             5e-5, 'subspace bf16x3 vs f32 path',
+                             max_flip_mag=5e-6)
