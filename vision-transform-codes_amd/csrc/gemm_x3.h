@@ -35,6 +35,24 @@ struct epi_whole_tile : std::false_type {};
 template <class E>
 struct epi_whole_tile<E, std::void_t<decltype(E::kWholeTile)>>
     : std::true_type {};
+// A whole-tile epilogue that also declares `kPrefetch` (floats per lane it
+// wants to read per tile) is run as a pipeline over the wave's four tiles:
+//   ctx = begin(m0, M)                 once per block
+//   load(ctx, row_in_block, col0, lane, N, buf)     issue the tile's reads
+//   finish(ctx, row_in_block, col0, lane, N, acc, buf)   compute and store
+// load(tile 0) is issued before the K loop, load(t+1) before finish(t): a
+// store orders later loads of the same array behind it, so without this each
+// tile would pay a full memory round trip.
+template <class E, class = void>
+struct epi_prefetch : std::false_type {};
+template <class E>
+struct epi_prefetch<E, std::void_t<decltype(E::kPrefetch)>> : std::true_type {};
+template <class E, bool = epi_prefetch<E>::value>
+struct epi_prefetch_floats { static constexpr int value = 1; };
+template <class E>
+struct epi_prefetch_floats<E, true> {
+  static constexpr int value = E::kPrefetch;
+};
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
@@ -125,6 +143,14 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr bool kPipe = epi_prefetch<Epi>::value;
+  float pre0[epi_prefetch_floats<Epi>::value],
+      pre1[epi_prefetch_floats<Epi>::value];
+  auto ctx = [&] {
+    if constexpr (kPipe) return epi.begin(m0, g.M); else return 0;
+  }();
+  if constexpr (kPipe) epi.load(ctx, wm * 64, n0 + wn * 64, lane, g.N, pre0);
+
   float4 ra[4], rb[4];
   x3_stage_load(g.A, g.lda, m0, g.M, k_begin, k_end, tid, ra);
   x3_stage_load(g.B, g.ldb, n0, g.N, k_begin, k_end, tid, rb);
@@ -181,7 +207,17 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
     cur ^= 1;
   }
 
-  if constexpr (epi_whole_tile<Epi>::value) {
+  if constexpr (kPipe) {
+    const int r0 = wm * 64;
+    const int64_t c0 = n0 + wn * 64;
+    epi.load(ctx, r0, c0 + 32, lane, g.N, pre1);
+    epi.finish(ctx, r0, c0, lane, g.N, acc[0][0], pre0);
+    epi.load(ctx, r0 + 32, c0, lane, g.N, pre0);
+    epi.finish(ctx, r0, c0 + 32, lane, g.N, acc[0][1], pre1);
+    epi.load(ctx, r0 + 32, c0 + 32, lane, g.N, pre1);
+    epi.finish(ctx, r0 + 32, c0, lane, g.N, acc[1][0], pre0);
+    epi.finish(ctx, r0 + 32, c0 + 32, lane, g.N, acc[1][1], pre1);
+  } else if constexpr (epi_whole_tile<Epi>::value) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

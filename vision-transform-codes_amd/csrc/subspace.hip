@@ -39,6 +39,7 @@ struct EpiGradStep {  // Y <- Y - eta * g
 template <int M>
 struct EpiGroupProx {
   static constexpr bool kWholeTile = true;
+  static constexpr int kPrefetch = 32;     // 16 of Y + 16 of the codes
   float* Y;
   float* C;
   int64_t ld;
@@ -46,39 +47,70 @@ struct EpiGroupProx {
   int fista;
   double* delta_sum;
   double local;
-  __device__ __forceinline__ void tile(int64_t row0, int64_t col0, int lane,
-                                       const f32x16& acc, int64_t rows,
-                                       int64_t cols) {
+  // rows of the block as buffer resources: a row past the batch is past the
+  // end of the resource (reads give 0, writes are dropped)
+  struct Ctx {
+    __amdgpu_buffer_rsrc_t yrs, crs;
+  };
+  __device__ __forceinline__ Ctx begin(int64_t m0, int64_t rows) const {
+    const int64_t left = rows - m0 < kX3BM ? rows - m0 : kX3BM;
+    const int bytes = (int)(left * ld * 4);
+    Ctx ctx;
+    ctx.yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + m0 * ld), 0, bytes,
+                                                0x00020000);
+    ctx.crs = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ld), 0, bytes,
+                                                0x00020000);
+    return ctx;
+  }
+  __device__ __forceinline__ unsigned lane_offset(int row0, int64_t col0,
+                                                  int lane,
+                                                  int64_t cols) const {
     const int64_t col = col0 + (lane & 31);
-    const bool col_ok = col < cols;
-    const int64_t rbase = row0 + 4 * (lane >> 5);
-    float y[16], c[16];
+    return col < cols ? (unsigned)(((int64_t)(row0 + 4 * (lane >> 5)) * ld +
+                                    col) * 4)
+                      : 0x80000000u;
+  }
+  __device__ __forceinline__ void load(const Ctx& ctx, int row0, int64_t col0,
+                                       int lane, int64_t cols,
+                                       float (&buf)[32]) const {
+    const unsigned off = lane_offset(row0, col0, lane, cols);
+    const unsigned ld4 = (unsigned)(ld * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-      const bool ok = col_ok && row < rows;
-      y[r] = ok ? Y[row * ld + col] : 0.f;
-      c[r] = ok ? C[row * ld + col] : 0.f;
+      const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * ld4;
+      buf[r] = __uint_as_float(
+          __builtin_amdgcn_raw_buffer_load_b32(ctx.yrs, off, so, 0));
+      buf[16 + r] = __uint_as_float(
+          __builtin_amdgcn_raw_buffer_load_b32(ctx.crs, off, so, 0));
     }
+  }
+  __device__ __forceinline__ void finish(const Ctx& ctx, int row0,
+                                         int64_t col0, int lane, int64_t cols,
+                                         const f32x16& acc,
+                                         const float (&buf)[32]) {
+    const unsigned off = lane_offset(row0, col0, lane, cols);
+    const unsigned ld4 = (unsigned)(ld * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
-      const bool ok = col_ok && row < rows;
-      const float p = ok ? sub_rn(y[r], mul_rn(eta, acc[r])) : 0.f;
+      const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * ld4;
+      // rows / columns outside the problem read as zero: p = 0, written
+      // nowhere
+      const float p = sub_rn(buf[r], mul_rn(eta, acc[r]));
       float sumsq = mul_rn(p, p);
 #pragma unroll
-      for (int off = 1; off < M; off <<= 1)
-        sumsq = add_rn(sumsq, __shfl_xor(sumsq, off, 64));
+      for (int o = 1; o < M; o <<= 1)
+        sumsq = add_rn(sumsq, __shfl_xor(sumsq, o, 64));
       float norm = sqrtf(sumsq);
       if (norm == 0.f) norm = 1.f;  // subspace_ista_fista.py:150
       const float scale = clamp_min0(sub_rn(1.f, cutoff / norm));
       const float cn = mul_rn(p, scale);
-      const float d = sub_rn(cn, c[r]);
-      if (ok) {
-        Y[row * ld + col] = fista ? add_rn(cn, mul_rn(beta, d)) : cn;
-        C[row * ld + col] = cn;
-        if (delta_sum) local += (double)(fabsf(d) / eta);
-      }
+      const float d = sub_rn(cn, buf[16 + r]);
+      __builtin_amdgcn_raw_buffer_store_b32(
+          __float_as_uint(fista ? add_rn(cn, mul_rn(beta, d)) : cn), ctx.yrs,
+          off, so, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cn), ctx.crs, off,
+                                            so, 0);
+      if (delta_sum) local += (double)(fabsf(d) / eta);
     }
   }
   __device__ __forceinline__ void operator()(int64_t, int64_t, float,
