@@ -39,7 +39,8 @@ struct epi_whole_tile<E, std::void_t<decltype(E::kWholeTile)>>
 // wants to read per tile) is run as a pipeline over the wave's four tiles:
 //   ctx = begin(m0, M)                 once per block
 //   load(ctx, row_in_block, col0, lane, N, buf)     issue the tile's reads
-//   finish(ctx, row_in_block, col0, lane, N, acc, buf)   compute and store
+//   finish(ctx, row_in_block, col0, lane, N, acc, buf, scratch)   compute and
+//       store; `scratch` = 8 KiB of LDS private to the wave
 // load(tile 0) is issued before the K loop, load(t+1) before finish(t): a
 // store orders later loads of the same array behind it, so without this each
 // tile would pay a full memory round trip.
@@ -56,6 +57,7 @@ struct epi_prefetch_floats<E, true> {
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kX3BM = 128, kX3BN = 128, kX3BK = 32;
 constexpr int kX3TileBytes = 128 * 64;   // one operand part: 128 rows x 64 B
@@ -210,13 +212,16 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   if constexpr (kPipe) {
     const int r0 = wm * 64;
     const int64_t c0 = n0 + wn * 64;
+    // the operand tiles are dead after the K loop (last barrier above): each
+    // wave stages its accumulator tiles through its own 8 KiB of them
+    float* scratch = reinterpret_cast<float*>(&lds[0][0][0]) + wave * 2048;
     epi.load(ctx, r0, c0 + 32, lane, g.N, pre1);
-    epi.finish(ctx, r0, c0, lane, g.N, acc[0][0], pre0);
+    epi.finish(ctx, r0, c0, lane, g.N, acc[0][0], pre0, scratch);
     epi.load(ctx, r0 + 32, c0, lane, g.N, pre0);
-    epi.finish(ctx, r0, c0 + 32, lane, g.N, acc[0][1], pre1);
+    epi.finish(ctx, r0, c0 + 32, lane, g.N, acc[0][1], pre1, scratch);
     epi.load(ctx, r0 + 32, c0 + 32, lane, g.N, pre1);
-    epi.finish(ctx, r0 + 32, c0, lane, g.N, acc[1][0], pre0);
-    epi.finish(ctx, r0 + 32, c0 + 32, lane, g.N, acc[1][1], pre1);
+    epi.finish(ctx, r0 + 32, c0, lane, g.N, acc[1][0], pre0, scratch);
+    epi.finish(ctx, r0 + 32, c0 + 32, lane, g.N, acc[1][1], pre1, scratch);
   } else if constexpr (epi_whole_tile<Epi>::value) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)

@@ -62,12 +62,20 @@ struct EpiGroupProx {
                                                 0x00020000);
     return ctx;
   }
+  // Global accesses are 16 bytes per lane: lane l owns row (l >> 3) + 8 q
+  // (q = 0..3) and columns 4 (l & 7) .. +3 of the 32 x 32 tile, so one wave
+  // instruction moves 8 full 128-byte row segments.  (The vector-memory
+  // address unit takes 16 cycles per wave instruction whatever the width: a
+  // dword per lane is a quarter of the 64 B/clk the CU can move.)  The
+  // accumulator tile (lane = column, register = row) is brought into that
+  // shape through the wave's slice of the block's LDS, free after the K loop.
+  static constexpr int kPitch = 36;        // floats per staged row
   __device__ __forceinline__ unsigned lane_offset(int row0, int64_t col0,
                                                   int lane,
                                                   int64_t cols) const {
-    const int64_t col = col0 + (lane & 31);
-    return col < cols ? (unsigned)(((int64_t)(row0 + 4 * (lane >> 5)) * ld +
-                                    col) * 4)
+    const int64_t col = col0 + 4 * (lane & 7);
+    return col < cols ? (unsigned)(((int64_t)(row0 + (lane >> 3)) * ld + col) *
+                                   4)
                       : 0x80000000u;
   }
   __device__ __forceinline__ void load(const Ctx& ctx, int row0, int64_t col0,
@@ -76,41 +84,75 @@ struct EpiGroupProx {
     const unsigned off = lane_offset(row0, col0, lane, cols);
     const unsigned ld4 = (unsigned)(ld * 4);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * ld4;
-      buf[r] = __uint_as_float(
-          __builtin_amdgcn_raw_buffer_load_b32(ctx.yrs, off, so, 0));
-      buf[16 + r] = __uint_as_float(
-          __builtin_amdgcn_raw_buffer_load_b32(ctx.crs, off, so, 0));
+    for (int q = 0; q < 4; ++q) {
+      const x3_u32x4 y4 = __builtin_amdgcn_raw_buffer_load_b128(
+          ctx.yrs, off, (unsigned)(8 * q) * ld4, 0);
+      const x3_u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(
+          ctx.crs, off, (unsigned)(8 * q) * ld4, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        buf[4 * q + i] = __uint_as_float(y4[i]);
+        buf[16 + 4 * q + i] = __uint_as_float(c4[i]);
+      }
     }
   }
   __device__ __forceinline__ void finish(const Ctx& ctx, int row0,
                                          int64_t col0, int lane, int64_t cols,
                                          const f32x16& acc,
-                                         const float (&buf)[32]) {
+                                         const float (&buf)[32],
+                                         float* scratch) {
     const unsigned off = lane_offset(row0, col0, lane, cols);
     const unsigned ld4 = (unsigned)(ld * 4);
+    // accumulator (column l & 31, rows (r&3) + 8 (r>>2) + 4 (l>>5)) -> LDS
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned so = (unsigned)((r & 3) + 8 * (r >> 2)) * ld4;
+    for (int r = 0; r < 16; ++r)
+      scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kPitch +
+              (lane & 31)] = acc[r];
+    float g[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(
+          scratch + ((lane >> 3) + 8 * q) * kPitch + 4 * (lane & 7));
+      g[4 * q + 0] = t.x; g[4 * q + 1] = t.y;
+      g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
       // rows / columns outside the problem read as zero: p = 0, written
       // nowhere
-      const float p = sub_rn(buf[r], mul_rn(eta, acc[r]));
-      float sumsq = mul_rn(p, p);
+      float p[4], sq[4];
 #pragma unroll
-      for (int o = 1; o < M; o <<= 1)
-        sumsq = add_rn(sumsq, __shfl_xor(sumsq, o, 64));
-      float norm = sqrtf(sumsq);
-      if (norm == 0.f) norm = 1.f;  // subspace_ista_fista.py:150
-      const float scale = clamp_min0(sub_rn(1.f, cutoff / norm));
-      const float cn = mul_rn(p, scale);
-      const float d = sub_rn(cn, buf[16 + r]);
-      __builtin_amdgcn_raw_buffer_store_b32(
-          __float_as_uint(fista ? add_rn(cn, mul_rn(beta, d)) : cn), ctx.yrs,
-          off, so, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cn), ctx.crs, off,
-                                            so, 0);
-      if (delta_sum) local += (double)(fabsf(d) / eta);
+      for (int i = 0; i < 4; ++i) {
+        p[i] = sub_rn(buf[4 * q + i], mul_rn(eta, g[4 * q + i]));
+        sq[i] = mul_rn(p[i], p[i]);
+      }
+      // group norm: M consecutive columns = M/4 lanes x 4, or parts of a lane
+      if (M == 2) {
+        sq[0] = sq[1] = add_rn(sq[0], sq[1]);
+        sq[2] = sq[3] = add_rn(sq[2], sq[3]);
+      } else if (M >= 4) {
+        float total = add_rn(add_rn(sq[0], sq[1]), add_rn(sq[2], sq[3]));
+#pragma unroll
+        for (int o = 1; o < M / 4; o <<= 1)
+          total = add_rn(total, __shfl_xor(total, o, 64));
+        sq[0] = sq[1] = sq[2] = sq[3] = total;
+      }
+      x3_u32x4 y4, c4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float norm = sqrtf(sq[i]);
+        if (norm == 0.f) norm = 1.f;  // subspace_ista_fista.py:150
+        const float scale = clamp_min0(sub_rn(1.f, cutoff / norm));
+        const float cn = mul_rn(p[i], scale);
+        const float d = sub_rn(cn, buf[16 + 4 * q + i]);
+        y4[i] = __float_as_uint(fista ? add_rn(cn, mul_rn(beta, d)) : cn);
+        c4[i] = __float_as_uint(cn);
+        if (delta_sum) local += (double)(fabsf(d) / eta);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yrs, off,
+                                             (unsigned)(8 * q) * ld4, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(c4, ctx.crs, off,
+                                             (unsigned)(8 * q) * ld4, 0);
     }
   }
   __device__ __forceinline__ void operator()(int64_t, int64_t, float,
