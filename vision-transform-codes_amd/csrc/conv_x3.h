@@ -396,7 +396,10 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     // a wave access is two 128-byte row segments.  (Measured alternative:
     // atoms on the lanes and 8- or 16-byte accesses along the row -- a quarter
     // of the instructions but 32 cache lines per instruction -- is 45%
-    // slower.)  Buffer addressing: lane offset + a scalar offset per register;
+    // slower; staging the tile through LDS for 16-byte accesses along the
+    // row, which pays off in the subspace epilogue where rows are 128-byte
+    // aligned, measures no gain here.)  Buffer addressing: lane offset + a
+    // scalar offset per register;
     // positions outside the code map get an out-of-range offset (loads give
     // 0, stores are dropped).
     auto tile_offset = [&](int t) -> unsigned {

@@ -108,6 +108,10 @@ struct EpiGroupProx {
     for (int r = 0; r < 16; ++r)
       scratch[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * kPitch +
               (lane & 31)] = acc[r];
+    // the reads below take what OTHER lanes just wrote: keep the compiler
+    // from moving them above the writes, and the next tile's writes above
+    // them (the LDS itself serves a wave's accesses in order)
+    asm volatile("" ::: "memory");
     float g[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -116,6 +120,7 @@ struct EpiGroupProx {
       g[4 * q + 0] = t.x; g[4 * q + 1] = t.y;
       g[4 * q + 2] = t.z; g[4 * q + 3] = t.w;
     }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       // rows / columns outside the problem read as zero: p = 0, written
