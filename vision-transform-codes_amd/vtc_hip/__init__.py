@@ -21,6 +21,7 @@ ISTA, FISTA = 0, 1
 SOFT, SOFT_NONNEG, HARD, HARD_NONNEG = range(4)
 F32, BF16X3, BF16 = range(3)
 PRECISIONS = {'f32': F32, 'bf16x3': BF16X3, 'bf16': BF16}
+ABI_VERSION = 2   # VTC_ABI_VERSION of include/vtc_hip.h this binding matches
 
 _lib = None
 
@@ -130,7 +131,7 @@ def load_library():
     fn = getattr(lib, name)   # AttributeError if the export is missing
     fn.restype = restype
     fn.argtypes = argtypes
-  if lib.vtc_abi_version() != 2:
+  if lib.vtc_abi_version() != ABI_VERSION:
     raise ImportError('libvtc_hip.so ABI version mismatch')
   _lib = lib
   return lib
