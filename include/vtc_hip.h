@@ -277,6 +277,19 @@ int vtc_extract_patches(const float* images, const int32_t* img_index,
                         float* patches, int64_t num, int32_t h, int32_t w,
                         int32_t c, int32_t ph, int32_t pw, void* stream);
 
+/* ---- ICA natural gradient (the sibling update
+ * rule dict_update_rules/fully_connected/ica_natural_gradient.py:26-35):
+ *   D += stepsize * ((codes^T sign(codes)) / b - I) D
+ * split at the quantity a data-parallel caller sums over ranks. */
+size_t vtc_ica_moment_workspace_bytes(int64_t b, int64_t s);
+/* moment_sum (s,s) = codes^T sign(codes): NOT divided by b */
+int vtc_ica_moment(const float* codes, float* moment_sum, int64_t b, int64_t s,
+                   void* workspace, size_t workspace_bytes, void* stream);
+size_t vtc_ica_apply_workspace_bytes(int64_t s, int64_t n);
+int vtc_ica_apply(float* dictionary, const float* moment_sum,
+                  int64_t global_batch, int64_t s, int64_t n, float stepsize,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

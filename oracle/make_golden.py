@@ -63,6 +63,8 @@ def import_reference():
       'dict_update_rules.convolutional.sc_steepest_descent')
   ref.conv_cq = importlib.import_module(
       'dict_update_rules.convolutional.sc_cheap_quadratic_descent')
+  ref.ica = importlib.import_module(
+      'dict_update_rules.fully_connected.ica_natural_gradient')
   ref.conv_utils = importlib.import_module('utils.convolutions')
   ref.trainer = importlib.import_module('training.sparse_coding')
   ref.image_processing = importlib.import_module('utils.image_processing')
@@ -448,6 +450,27 @@ def make_trainer(ref):
   np.savez_compressed(GOLDEN / 'trainer.npz', **out)
 
 
+def make_ica(ref):
+  """F8: the ICA natural-gradient update rule (f4 sibling of the dictionary
+  update plugins) on sparse codes, one and three iterations, square and
+  overcomplete dictionaries."""
+  out = {}
+  X = gaussian_patches(70, 200, 64)
+  for tag, s_atoms in (('square', 64), ('wide', 96)):
+    D0 = unit_rows(71 + s_atoms, s_atoms, 64)
+    C = ref.fc_inf.run(T(X), T(D0), 0.02, 10, variant='fista')
+    out[tag + '_dictionary0'] = D0
+    out[tag + '_codes'] = C.numpy()
+    for iters in (1, 3):
+      Dref = T(D0.copy())
+      ref.ica.run(Dref, C, stepsize=0.01, num_iters=iters)
+      Dm = T(D0.copy())
+      sc_oracle.ica_natural_gradient(Dm, C, stepsize=0.01, num_iters=iters)
+      report('ica %s %d iters' % (tag, iters), Dm, Dref)
+      out['%s_dictionary_after_%d' % (tag, iters)] = Dref.numpy().copy()
+  np.savez_compressed(GOLDEN / 'ica.npz', **out)
+
+
 class _RecordingWriter(object):
   """Stand-in for torch.utils.tensorboard.SummaryWriter (tensorboard is not
   installed): keeps the scalars the reference sends, ignores the images."""
@@ -599,7 +622,7 @@ def make_whitened(ref):
 MAKERS = {'fc_c1': make_fc_c1, 'fc_c2_mini': make_fc_c2_mini,
           'subspace': make_subspace, 'conv': make_conv,
           'trainer': make_trainer, 'whitened': make_whitened,
-          'metrics': make_metrics}
+          'metrics': make_metrics, 'ica': make_ica}
 
 
 def main(argv):

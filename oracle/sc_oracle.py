@@ -539,6 +539,18 @@ def hessian_diag_ema_(hessian_diagonal, codes):
   return hessian_diagonal
 
 
+def ica_natural_gradient(dictionary, codes, stepsize=0.001, num_iters=1):
+  """Restates vtc/dict_update_rules/fully_connected/ica_natural_gradient.py
+  :26-35.  Updates `dictionary` in place (gradient ASCENT)."""
+  eye_mat = torch.eye(codes.size(1), dtype=codes.dtype)
+  for _ in range(num_iters):
+    dict_update = stepsize * torch.mm(
+        (torch.mm(codes.t(), torch.sign(codes)) / codes.size(0)) - eye_mat,
+        dictionary)
+    dictionary.add_(dict_update)
+  return dictionary
+
+
 def compute_metrics(batch_images, batch_codes, dictionary,
                     previous_dictionary, sparsity_weight, params):
   """Restates the `compute_metrics` closure of

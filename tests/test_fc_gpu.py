@@ -233,3 +233,22 @@ def test_gradient_is_reproducible_and_linear(device, plugins):
   assert helpers.rel_err(halves.cpu().numpy(), full.cpu().numpy()) < 1e-6
   ref = (C.double().t() @ (C.double() @ D.double() - X.double()))
   assert helpers.rel_err(full.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+def test_ica_natural_gradient_update(device):
+  """The sibling update rule of the plugin API:
+  D += stepsize ((C^T sign(C)) / b - I) D, against the reference's output
+  (exact-f32 MFMA contractions, 2e-6 relative on the dictionary)."""
+  from dict_update_rules.fully_connected import ica_natural_gradient
+  g = helpers.load('ica')
+  for tag in ('square', 'wide'):
+    C = helpers.to_dev(g[tag + '_codes'], device)
+    C0 = C.clone()
+    for iters in (1, 3):
+      D = helpers.to_dev(g[tag + '_dictionary0'].copy(), device)
+      assert ica_natural_gradient.run(D, C, stepsize=0.01,
+                                      num_iters=iters) is None
+      assert helpers.rel_err(
+          D.cpu().numpy(),
+          g['%s_dictionary_after_%d' % (tag, iters)]) < helpers.REL_TOL_DICT
+    assert torch.equal(C, C0)

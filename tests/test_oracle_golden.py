@@ -234,6 +234,17 @@ def test_validation_metrics():
     assert helpers.rel_err(D.numpy(), g[tag + '_dictionary_final']) < 2e-6
 
 
+def test_ica_natural_gradient():
+  g = helpers.load('ica')
+  for tag in ('square', 'wide'):
+    for iters in (1, 3):
+      D = T(g[tag + '_dictionary0'].copy())
+      sc_oracle.ica_natural_gradient(D, T(g[tag + '_codes']), stepsize=0.01,
+                                     num_iters=iters)
+      assert helpers.rel_err(
+          D.numpy(), g['%s_dictionary_after_%d' % (tag, iters)]) < 1e-7
+
+
 def test_whitened_patches():
   g = helpers.load('whitened')
   X = T(g['images'])

@@ -305,6 +305,49 @@ extern "C" int vtc_fc_dict_gradient(const float* images,
   return launch_slab_reduce(slabs, slices, s * n, grad_sum, st);
 }
 
+// ---------------------------------------------- ICA natural gradient (f4)
+// dict_update_rules/fully_connected/ica_natural_gradient.py:26-35:
+//   D += stepsize * ((C^T sign(C)) / b - I) D
+// split like the sparse-coding update: the (s, s) moment C^T sign(C) is the
+// quantity a data-parallel caller sums over ranks.
+__global__ void sign_kernel(const float* __restrict__ x, float* __restrict__ y,
+                            int64_t count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    y[i] = sign_of(x[i]);
+}
+
+// T = M / b - I
+__global__ void ica_center_kernel(const float* __restrict__ moment_sum,
+                                  float* __restrict__ T, float batch_f,
+                                  int64_t s) {
+  const int64_t total = s * s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += stride) {
+    const float eye = (i / s == i % s) ? 1.f : 0.f;
+    T[i] = sub_rn(moment_sum[i] / batch_f, eye);
+  }
+}
+
+// D += stepsize * U   (the reference ascends: dictionary.add_)
+__global__ void axpy_rn_kernel(float* __restrict__ D,
+                               const float* __restrict__ U, float stepsize,
+                               int64_t count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += stride)
+    D[i] = add_rn(D[i], mul_rn(stepsize, U[i]));
+}
+
+static unsigned stream_grid(int64_t total) {
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
 // E = codes * dictionary - images  (the reconstruction residual; the trainer's
 // validation metrics, training/sparse_coding.py:181-203)
 extern "C" int vtc_fc_residual(const float* images, const float* dictionary,
@@ -425,6 +468,71 @@ extern "C" int vtc_hessian_ema(float* hessian_diagonal, const float* energy,
   hipLaunchKernelGGL(hessian_ema_kernel, dim3((unsigned)ceil_div(s, 256)),
                      dim3(256), 0, as_stream(stream), hessian_diagonal, energy,
                      (float)global_batch, s);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+extern "C" size_t vtc_ica_moment_workspace_bytes(int64_t b, int64_t s) {
+  if (b <= 0 || s <= 0) return 256;
+  return align_up((size_t)b * s * sizeof(float), 256) +
+         align_up((size_t)gradient_slices(b, s, s) * s * s * sizeof(float),
+                  256);
+}
+
+extern "C" int vtc_ica_moment(const float* codes, float* moment_sum, int64_t b,
+                              int64_t s, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  VTC_REQUIRE(codes && moment_sum, "vtc_ica_moment: null pointer");
+  VTC_REQUIRE(b > 0 && s > 0, "vtc_ica_moment: bad sizes");
+  if (!workspace || workspace_bytes < vtc_ica_moment_workspace_bytes(b, s)) {
+    set_error("vtc_ica_moment: workspace too small");
+    return VTC_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver ws(workspace);
+  float* S = ws.take<float>((size_t)b * s);
+  const int slices = gradient_slices(b, s, s);
+  float* slabs = ws.take<float>((size_t)slices * s * s);
+  hipLaunchKernelGGL(sign_kernel, dim3(stream_grid(b * s)), dim3(256), 0, st,
+                     codes, S, b * s);
+  VTC_LAUNCH_CHECK();
+  // M = C^T sign(C), K = b split into slabs summed in a fixed order
+  EpiSlab e{slabs, s * s, s};
+  int rc = launch_gemm_f32<false, false>(codes, s, S, s, s, s, b, slices, e,
+                                         st);
+  if (rc != VTC_OK) return rc;
+  return launch_slab_reduce(slabs, slices, s * s, moment_sum, st);
+}
+
+extern "C" size_t vtc_ica_apply_workspace_bytes(int64_t s, int64_t n) {
+  if (s <= 0 || n <= 0) return 256;
+  return align_up((size_t)s * s * sizeof(float), 256) +
+         align_up((size_t)s * n * sizeof(float), 256);
+}
+
+extern "C" int vtc_ica_apply(float* dictionary, const float* moment_sum,
+                             int64_t global_batch, int64_t s, int64_t n,
+                             float stepsize, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  VTC_REQUIRE(dictionary && moment_sum, "vtc_ica_apply: null pointer");
+  VTC_REQUIRE(global_batch > 0 && s > 0 && n > 0, "vtc_ica_apply: bad sizes");
+  if (!workspace || workspace_bytes < vtc_ica_apply_workspace_bytes(s, n)) {
+    set_error("vtc_ica_apply: workspace too small");
+    return VTC_ERR_WORKSPACE;
+  }
+  hipStream_t st = as_stream(stream);
+  Carver ws(workspace);
+  float* T = ws.take<float>((size_t)s * s);
+  float* U = ws.take<float>((size_t)s * n);
+  hipLaunchKernelGGL(ica_center_kernel, dim3(stream_grid(s * s)), dim3(256), 0,
+                     st, moment_sum, T, (float)global_batch, s);
+  VTC_LAUNCH_CHECK();
+  EpiStore e{U, n};
+  int rc = launch_gemm_f32<true, false>(T, s, dictionary, n, s, n, s, 1, e,
+                                        st);
+  if (rc != VTC_OK) return rc;
+  hipLaunchKernelGGL(axpy_rn_kernel, dim3(stream_grid(s * n)), dim3(256), 0,
+                     st, dictionary, U, stepsize, s * n);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }

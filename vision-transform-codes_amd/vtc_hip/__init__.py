@@ -89,6 +89,11 @@ SIGNATURES = {
                                           _f32, _f32, _i32, _vp, _sz, _vp]),
     'vtc_extract_patches': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                    _i32, _i32, _i32, _vp]),
+    'vtc_ica_moment_workspace_bytes': (_sz, [_i64, _i64]),
+    'vtc_ica_moment': (_i32, [_vp, _vp, _i64, _i64, _vp, _sz, _vp]),
+    'vtc_ica_apply_workspace_bytes': (_sz, [_i64, _i64]),
+    'vtc_ica_apply': (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _vp, _sz,
+                             _vp]),
     'vtc_conv_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _f32, _f32,
                                    _i32, _i32, _i32, _f32, _i32, _vp, _sz,
                                    ctypes.POINTER(_i32), _vp]),
