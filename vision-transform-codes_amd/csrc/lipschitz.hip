@@ -7,8 +7,8 @@
 // eigen-decomposition of a 256 x 256 matrix costs ~4 ms on MI355X (measured:
 // 5 % of a whole training step).  Only the top eigenvalue is needed, so this is a
 // single-workgroup Lanczos iteration with full re-orthogonalisation (the
-// Krylov basis lives in LDS), followed by bisection on the tridiagonal
-// matrix with Sturm counts, in double precision, on one lane.  For n <= 128
+// Krylov basis lives in LDS), followed by 64-way sectioning on the tridiagonal
+// matrix with Sturm counts, in double precision, by one wave.  For n <= 128
 // the Krylov space is the whole space and the result is the exact top
 // eigenvalue up to rounding; for n <= 256, 128 steps converge to f32
 // resolution on the spectra of interest (extreme eigenvalue, Kaniel-Paige).
@@ -33,9 +33,14 @@ __device__ __forceinline__ double block_sum_vec(double v, double* red) {
 }
 
 // Largest eigenvalue of the symmetric tridiagonal matrix (alpha, beta) of
-// order m by bisection on Sturm counts, double precision, one lane.
+// order m from Sturm counts, double precision, by ONE WAVE (all 64 lanes call
+// it with the same arguments and get the same result): every round each lane
+// takes the Sturm count at one of 64 interior points of the bracket, which
+// shrinks 65x per round (a one-lane bisection, 50 rounds of an m-long chain of
+// divisions at every convergence check, was 1 ms of the 1.1 ms this kernel took).
 __device__ double tridiagonal_lambda_max(const double* alpha,
                                          const double* beta, int m) {
+  const int lane = threadIdx.x & 63;
   double lo = alpha[0], hi = alpha[0];
   for (int i = 0; i < m; ++i) {
     const double off = (i > 0 ? fabs(beta[i - 1]) : 0.0) +
@@ -44,10 +49,11 @@ __device__ double tridiagonal_lambda_max(const double* alpha,
     hi = fmax(hi, alpha[i] + off);
   }
   if (!(hi == hi) || !(lo == lo)) return hi + lo;  // NaN propagates
-  // smallest x with (#eigenvalues < x) == m
-  for (int it = 0; it < 200 && hi - lo > 1e-14 * fmax(fabs(hi), fabs(lo));
+  // invariant: count(lo) < m <= count(hi), count(x) = #eigenvalues < x
+  for (int it = 0; it < 40 && hi - lo > 1e-14 * fmax(fabs(hi), fabs(lo));
        ++it) {
-    const double x = 0.5 * (lo + hi);
+    const double step = (hi - lo) / 65.0;
+    const double x = lo + step * (double)(lane + 1);
     int below = 0;
     double d = 1.0;
     for (int i = 0; i < m; ++i) {
@@ -56,7 +62,16 @@ __device__ double tridiagonal_lambda_max(const double* alpha,
       if (d == 0.0) d = -1e-300;
       if (d < 0.0) ++below;
     }
-    if (below == m) hi = x; else lo = x;
+    // the lanes whose point is above the top eigenvalue form a suffix
+    const unsigned long long above = __ballot(below == m);
+    if (above == 0ull) {
+      lo = lo + step * 64.0;
+    } else {
+      const int first = __ffsll((long long)above) - 1;
+      const double new_hi = lo + step * (double)(first + 1);
+      if (first > 0) lo = lo + step * (double)first;
+      hi = new_hi;
+    }
   }
   return 0.5 * (lo + hi);
 }
@@ -171,11 +186,14 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
     // every 8 steps: has the top Ritz value stopped moving?  (it grows
     // monotonically with the Krylov dimension)
     if ((j & 7) == 7) {
-      if (tid == 0) {
+      __syncthreads();                 // alpha[j], beta[j] visible to wave 0
+      if (wave == 0) {
         const double ritz = tridiagonal_lambda_max(alpha, beta, j + 1);
-        stop_flag = (last_ritz > 0.0 &&
-                     fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
-        last_ritz = ritz;
+        if (tid == 0) {
+          stop_flag = (last_ritz > 0.0 &&
+                       fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
+          last_ritz = ritz;
+        }
       }
       __syncthreads();
       if (stop_flag) {
@@ -189,11 +207,13 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
   }
   __syncthreads();
 
-  if (tid == 0) {
+  if (wave == 0) {
     const double lambda = tridiagonal_lambda_max(alpha, beta, steps_done);
     const float lf = (float)lambda;
-    out[0] = lf;
-    out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+    if (tid == 0) {
+      out[0] = lf;
+      out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+    }
   }
 }
 
