@@ -214,6 +214,7 @@ struct ProxParams {
 }  // namespace vtc
 #include "conv_unit.h"
 #include "conv_x3.h"
+#include "conv_patch.h"
 namespace vtc {
 
 __global__ __launch_bounds__(256) void conv_analysis_prox_kernel(
@@ -441,6 +442,7 @@ static size_t conv_inference_ws(const ConvGeo& g) {
                                                               // <= 8 partials
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
          conv_x3_image_bytes(g) +                             // bf16x3 operands
+         patch_workspace_bytes(g) +                           // im2col, Q
          256;
 }
 
@@ -541,6 +543,14 @@ extern "C" int vtc_conv_ista_fista(
     rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
     if (rc != VTC_OK) return rc;
   }
+  const bool patch_path = !x3 && patch_geometry(g);
+  float* patches = nullptr;
+  float* contributions = nullptr;
+  if (patch_path) {
+    const size_t elems = (size_t)g.b * g.ch * g.cw * ctaps;
+    patches = ws.take<float>(elems);
+    contributions = ws.take<float>(elems);
+  }
   double* delta_sum = ws.take<double>(1);
   const bool fista = (variant == VTC_FISTA);
   float* Y = fista ? Ybuf : codes;
@@ -585,6 +595,13 @@ extern "C" int vtc_conv_ista_fista(
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
       if (rc != VTC_OK) return rc;
       rc = cx_launch_analysis(residual, ana_image, Y, codes, g, xp, pp, st);
+      if (rc != VTC_OK) return rc;
+    } else if (patch_path) {
+      // strides > 1: both convolutions as exact-f32 patch contractions
+      rc = patch_synthesis(Y, dictionary, images_padded, residual,
+                           contributions, g, st);
+      if (rc != VTC_OK) return rc;
+      rc = patch_analysis(residual, dictionary, Y, codes, patches, g, pp, st);
       if (rc != VTC_OK) return rc;
     } else if (unit_path) {
       // stride-1 square kernels: scalar-tap kernels, the kernel sum of the

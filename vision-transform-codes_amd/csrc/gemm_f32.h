@@ -35,6 +35,9 @@ struct GemmArgs {
   int64_t lda, ldb;
   int64_t k_chunk;   // multiple of kGemmBK
   int a_vec, b_vec;  // 16-byte vector loads allowed for this operand
+  // batch (blockIdx.z): operand offsets in elements per batch entry; the
+  // epilogue sees row + batch * M, i.e. the batches stacked along the rows
+  int64_t a_batch, b_batch;
 };
 
 __device__ __forceinline__ float4 load4_guarded(const float* p, int64_t avail,
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
   const int64_t k_begin = (int64_t)z * g.k_chunk;
   const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
   const int nk = (int)((k_end - k_begin + kGemmBK - 1) / kGemmBK);
+  g.A += (int64_t)blockIdx.z * g.a_batch;
+  g.B += (int64_t)blockIdx.z * g.b_batch;
+  const int64_t row_shift = (int64_t)blockIdx.z * g.M;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
       for (int r = 0; r < 16; ++r) {
         const int64_t row =
             m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N) epi(row, col, acc[mi][ni][r], z);
+        if (row < g.M && col < g.N)
+          epi(row + row_shift, col, acc[mi][ni][r], z);
       }
     }
   }
@@ -183,8 +190,14 @@ static inline int gemm_vec_ok(const float* p, int64_t ld) {
 template <bool A_KC, bool B_KC, class Epi>
 static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
                            int64_t ldb, int64_t M, int64_t N, int64_t K,
-                           int k_slices, Epi epi, hipStream_t st) {
-  if (M <= 0 || N <= 0) return VTC_OK;
+                           int k_slices, Epi epi, hipStream_t st,
+                           int64_t batches = 1, int64_t a_batch = 0,
+                           int64_t b_batch = 0) {
+  if (M <= 0 || N <= 0 || batches <= 0) return VTC_OK;
+  if (batches > 65535) {
+    set_error("gemm: too many batch entries (%lld)", (long long)batches);
+    return VTC_ERR_INVALID_ARGUMENT;
+  }
   GemmArgs g;
   g.A = A;
   g.B = B;
@@ -197,14 +210,16 @@ static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
   int64_t chunk = ceil_div(ceil_div(K, k_slices), kGemmBK) * kGemmBK;
   if (chunk < kGemmBK) chunk = kGemmBK;
   g.k_chunk = chunk;
-  g.a_vec = gemm_vec_ok(A, lda);
-  g.b_vec = gemm_vec_ok(B, ldb);
+  g.a_vec = gemm_vec_ok(A, lda) && (a_batch % 4 == 0);
+  g.b_vec = gemm_vec_ok(B, ldb) && (b_batch % 4 == 0);
+  g.a_batch = a_batch;
+  g.b_batch = b_batch;
   const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
   if (tiles > 0x7fffffffLL) {
     set_error("gemm: too many tiles (%lld)", (long long)tiles);
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  dim3 grid((unsigned)tiles, (unsigned)k_slices, 1);
+  dim3 grid((unsigned)tiles, (unsigned)k_slices, (unsigned)batches);
   hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, Epi>), grid,
                      dim3(kGemmThreads), 0, st, g, epi);
   VTC_LAUNCH_CHECK();
