@@ -35,6 +35,8 @@ FLOP_PER_PATCH_ITER = 4 * N_ATOMS * N_PIX     # two contractions of 2*s*n
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
 PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3}
+# a pure MFMA loop on the box (tools/peaks/peaks.hip, profiles/r01_peaks.txt)
+MEASURED_PEAK_TFLOPS = {'bf16': 2030.0, 'bf16x3': 2030.0, 'f32': 144.0}
 KERNEL_NAMES = {
     'bf16': 'vtc::fused_fista_kernel<8,1,SOFT> (one launch = all 200 '
             'iterations, state on chip)',
@@ -218,9 +220,13 @@ def main():
           'frac': achieved / peak, 'traffic': traffic,
           'ms_per_launch': kernel_ms,
           'flops_per_launch': flops_per_launch,
+          'peak_measured': MEASURED_PEAK_TFLOPS[precision],
+          'frac_of_measured_peak': achieved / MEASURED_PEAK_TFLOPS[precision],
           'note': 'algorithmic flops 4*s*n per patch-iteration; bf16x3 issues '
                   '3 MFMA products per algorithmic product, so its MFMA pipe '
-                  'utilisation is 3x this fraction'},
+                  'utilisation is 3x this fraction; the kernel is bound by '
+                  'the L2->VGPR streaming rate of a CU (dictionary fragments: '
+                  '52.8 of a measured 58 B/clk/CU, profiles/r01_peaks.txt)'},
   }
   if world == 1 and precision != 'bf16' and ista_fista.fused_available():
     # the bf16 fast mode on the same inputs, reported beside the headline
