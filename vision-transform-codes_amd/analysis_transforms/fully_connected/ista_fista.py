@@ -39,8 +39,10 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
   precision : None | 'auto' | 'f32' | 'bf16x3' | 'bf16' -- extension, see
       vtc_hip.set_default_precision.  None uses the process-wide default.
       'bf16x3' runs the fused persistent kernel when the shape allows
-      (n == 256, s in {256, 512, 1024}, no early stopping) and a tiled
+      (n == 256, s a multiple of 128, no early stopping) and a tiled
       bf16 hi/lo split contraction otherwise; 'bf16' exists only fused.
+      'auto' = 'bf16x3' for the fused kernel's shapes and for large problems
+      (b*s >= 2^22, n and s multiples of 4), 'f32' otherwise.
   stepsize : float, optional -- extension: skip the Lipschitz eigen-solve and
       use this eta (tests inject the eta of a golden vector this way).
 
@@ -96,9 +98,15 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
   name = precision if precision is not None else (
       vtc_hip.get_default_precision())
   if name == 'auto':
+    # the default policy: bf16x3 (float32-level results, tests bound it at the
+    # same tolerance as the exact kernels) wherever it pays -- the fused
+    # kernel's shapes, and large problems on the tiled contraction; the exact
+    # f32 kernels for small or oddly sized ones
     fused_ok = (early_stopping_epsilon is None and n == 256 and
                 s % 128 == 0 and fused_available())
-    return vtc_hip.BF16X3 if fused_ok else vtc_hip.F32
+    tiled_ok = (n % 4 == 0 and s % 4 == 0 and b * s >= (1 << 22) and
+                fused_available())
+    return vtc_hip.BF16X3 if (fused_ok or tiled_ok) else vtc_hip.F32
   return vtc_hip.PRECISIONS[name]
 
 
