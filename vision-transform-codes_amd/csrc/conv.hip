@@ -5,13 +5,19 @@
 //   dict_update_rules/convolutional/sc_steepest_descent.py:54-72
 //   dict_update_rules/convolutional/sc_cheap_quadratic_descent.py:59-79
 //   utils/convolutions.py:14-24
-// without im2col buffers in HBM: every kernel stages the code window / the
-// residual window of its tile in LDS and walks the kernel taps there.
-//
-// Exact f32 throughout.  On gfx950 the f32-input MFMA runs at the f32 VALU
-// rate, so for an exact-f32 convolution the matrix cores buy no arithmetic
-// throughput; these are direct (VALU) convolutions, deterministic in their
-// summation order.
+// Four routes, chosen per geometry and precision in vtc_conv_ista_fista:
+//   conv_x3.h     one channel, stride 1, square kernels 5/8/11/16, VTC_BF16X3:
+//                 both convolutions as split-bf16 MFMA contractions
+//   conv_unit.h   stride 1, square kernels, VTC_F32: direct f32 kernels with
+//                 scalar taps
+//   conv_patch.h  strides > 1 with few covering positions, VTC_F32: exact-f32
+//                 MFMA contractions over an im2col copy of the residual
+//   this file     everything else: direct f32 kernels, the code window / the
+//                 residual window of a tile staged in LDS
+// plus the convolutional dictionary gradient / apply kernels.  None writes an
+// im2col buffer for stride 1.  The VTC_F32 routes are exact f32 with fixed
+// summation orders (on gfx950 the f32-input MFMA runs at the f32 VALU rate, so
+// for a direct exact-f32 convolution the matrix cores buy nothing).
 //
 // Index conventions (b image, s kernel, c channel, (p,q) code position,
 // (y,x) padded-image pixel, (dy,dx) kernel tap):

@@ -5,11 +5,14 @@
 // dictionary into a (G*m, n) matrix with duplicated rows for atoms that sit in
 // several groups; the same layout is used here, so the two contractions are
 // the fully-connected ones on G*m "slots".  Per iteration:
-//     R = Y Dg - X                               exact-f32 MFMA
-//     P = Y - eta * (R Dg^T)                     epilogue, in place over Y
+//     R = Y Dg - X            exact-f32 MFMA, or bf16x3 tiles (split over the
+//                             slot axis when n gives too few output tiles)
+//     P = Y - eta * (R Dg^T)
 //     C = P * max(1 - lambda*eta / ||P_group||, 0);  Y = C + beta (C - C_prev)
-//                                                one pass, a thread per
-//                                                (patch, group)
+// bf16x3: the second product carries the last two lines in its epilogue
+// (epi_prox.h) for group sizes that are powers of two <= 32; otherwise, and on
+// the exact-f32 path, P is written by the product and one of the proximal
+// kernels below follows.
 #include "common.h"
 #include "gemm_f32.h"
 #include "gemm_x3.h"
