@@ -185,6 +185,38 @@ def test_bf16x3_tiled_contraction_outside_the_fused_kernel(device, ista_fista,
                              max_flip_mag=5e-6)
 
 
+def test_bf16x3_tiled_path_variants_and_thresholds(device, ista_fista):
+  """The tiled bf16x3 path (16-byte proximal epilogue of epi_prox.h): ISTA
+  (gradient point and codes share one buffer), the non-negative soft
+  threshold, warm start, a batch that is not a multiple of the 128-row tile,
+  and bitwise reproducibility."""
+  b, n, s = 333, 100, 200
+  Xn = helpers.gaussian_patches(910, b, n)
+  Dn = helpers.unit_rows(911, s, n)
+  Xc, Dc = torch.from_numpy(Xn), torch.from_numpy(Dn)
+  X, D = helpers.to_dev(Xn, device), helpers.to_dev(Dn, device)
+  eta = sc_oracle.fc_stepsize(Dc)
+  for kw in ({'variant': 'ista'}, {'nonnegative_only': True},
+             {'variant': 'ista', 'nonnegative_only': True}):
+    ref = sc_oracle.fc_ista_fista(Xc, Dc, 0.03, 25, stepsize=eta, **kw)
+    out = ista_fista.run(X, D, 0.03, 25, precision='bf16x3',
+                         stepsize=float(eta), **kw)
+    helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                               'tiled bf16x3 %r' % kw, max_flip_mag=5e-6)
+  warm = sc_oracle.fc_ista_fista(Xc, Dc, 0.03, 5, stepsize=eta)
+  ref = sc_oracle.fc_ista_fista(Xc, Dc, 0.03, 10, stepsize=eta,
+                                initial_codes=warm)
+  init = helpers.to_dev(warm.numpy(), device)
+  keep = init.clone()
+  out = ista_fista.run(X, D, 0.03, 10, precision='bf16x3', stepsize=float(eta),
+                       initial_codes=init)
+  again = ista_fista.run(X, D, 0.03, 10, precision='bf16x3',
+                         stepsize=float(eta), initial_codes=init)
+  assert torch.equal(init, keep) and torch.equal(out, again)
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                             'tiled bf16x3 warm start', max_flip_mag=5e-6)
+
+
 def test_bf16x3_with_early_stopping_uses_the_tiled_path(device, ista_fista):
   g = helpers.load('fc_c1')
   X, D = helpers.to_dev(g['images'], device), helpers.to_dev(
