@@ -283,10 +283,12 @@ static inline int gemm_x3_slices(int64_t K, int k_slices) {
   return (int)ceil_div(K, chunk);
 }
 
-// how many K slices give a contraction with few output tiles enough blocks
+// how many K slices give a contraction with few output tiles enough blocks:
+// one resident set (2 blocks per CU x 256 CUs) -- measured on configs[3]:
+// 256 / 384 / 512 / 1024 / 2048 blocks -> 45.9 / 44.0 / 41.9 / 44.9 / 51.3 ms
 static inline int gemm_x3_want_slices(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, kX3BM) * ceil_div(N, kX3BN);
-  int64_t want = ceil_div(1024, tiles);
+  int64_t want = ceil_div(512, tiles);
   const int64_t cap = ceil_div(K, 256);
   if (want > cap) want = cap;
   if (want > 16) want = 16;
