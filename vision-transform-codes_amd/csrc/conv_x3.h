@@ -39,7 +39,8 @@ constexpr int kCxStrip = 64;       // code columns per wave unit (2 MFMA tiles)
 constexpr int kCxSynWaves = 8;
 constexpr int kCxSynMaxRows = 8;   // code rows per wave (synthesis): 2 .. 8,
                                    // chosen per launch (cx_pick_rows)
-constexpr int kCxAnaRows = 8;      // code rows per block (analysis)
+constexpr int kCxAnaMaxRows = 8;   // code rows per block (analysis): 4 or 8,
+                                   // chosen per launch (cx_fill_plan)
 constexpr int kCxAnaPitch = 88;    // window row pitch, bf16 elements
 
 template <int K>
@@ -335,13 +336,13 @@ template <int MA, bool FAST>
 __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
-    int tiles_u, int chunks, ProxParams pp) {
+    int tiles_u, int chunks, int ana_rows, ProxParams pp) {
   constexpr int AC = 32 * MA;
   extern __shared__ __attribute__((aligned(16))) char cx_lds[];
   char* lds = cx_lds;
   const int k = g.kh;
   const int plane = k * AC * 16;                   // elements
-  const int rows = kCxAnaRows + k - 1;
+  const int rows = ana_rows + k - 1;
   uint16_t* Dh = reinterpret_cast<uint16_t*>(lds);
   uint16_t* Dl = Dh + plane;
   uint16_t* Rh = Dl + plane;
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int chunk = (int)(band % chunks);
   const int tile_u = (int)((band / chunks) % tiles_u);
   const int64_t img = band / ((int64_t)chunks * tiles_u);
-  const int u0 = tile_u * kCxAnaRows, v0 = tile_v * kCxStrip;
+  const int u0 = tile_u * ana_rows, v0 = tile_v * kCxStrip;
   {
     const uint4* src = reinterpret_cast<const uint4*>(
         ana_image + (int64_t)chunk * 2 * plane);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       (void*)(C + img * g.s * map), 0, code_bytes, 0x00020000);
   const bool ragged = (g.s % AC) != 0;
   double local = 0.0;
-  for (int pass = 0; pass < kCxAnaRows / 4; ++pass) {
+  for (int pass = 0; pass < ana_rows / 4; ++pass) {
     const int lu = wave + 4 * pass;
     const int u = u0 + lu;
     if (u >= g.ch) continue;                       // whole wave
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
 struct CxPlan {
   int k, s16, slots, AC, chunks;
   int syn_rows;      // code rows per wave of the synthesis kernel
+  int ana_rows;      // code rows per block of the analysis kernel
   size_t syn_image_bytes, ana_image_bytes;
   size_t syn_lds, ana_lds;
   int th, tw;
@@ -582,8 +584,17 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   p->th = kCxSynWaves * p->syn_rows - (K - 1);
   p->syn_lds = p->syn_image_bytes +
                (size_t)kCxSynWaves * p->th * Dm::PW * sizeof(float);
+  // Code rows per analysis block.  Two blocks per CU are resident; with few
+  // rounds of blocks the shorter tile fills them better, with many the taller
+  // one reloads the kernel planes half as often (same-box A/B: configs[4],
+  // b = 8: 10.44 vs 10.60 ms; 512x512 images: 34.87 vs 34.44 ms).
+  {
+    const int64_t blocks8 = ceil_div(g.cw, kCxStrip) *
+                            ceil_div(g.ch, kCxAnaMaxRows) * p->chunks * g.b;
+    p->ana_rows = blocks8 < (int64_t)16 * cx_compute_units() ? 4 : 8;
+  }
   p->ana_lds = (size_t)2 * K * p->AC * 16 * 2 +
-               (size_t)2 * (kCxAnaRows + K - 1) * kCxAnaPitch * 2;
+               (size_t)2 * (p->ana_rows + K - 1) * kCxAnaPitch * 2;
   p->tw = Dm::TW;
 }
 
@@ -657,7 +668,7 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 float* C, const ConvGeo& g, const CxPlan& p,
                                 const ProxParams& pp, hipStream_t st) {
   const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
-  const int tiles_u = (int)ceil_div(g.ch, kCxAnaRows);
+  const int tiles_u = (int)ceil_div(g.ch, p.ana_rows);
   static bool attr_set = false;
   if (!attr_set) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
@@ -673,7 +684,7 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
   }
   hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST>),
                      dim3((unsigned)blocks), dim3(256), p.ana_lds, st, R, ana,
-                     Y, C, g, tiles_v, tiles_u, p.chunks, pp);
+                     Y, C, g, tiles_v, tiles_u, p.chunks, p.ana_rows, pp);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
