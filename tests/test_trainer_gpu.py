@@ -94,6 +94,37 @@ def test_validation_metrics(device, tag):
   assert helpers.rel_err(D.cpu().numpy(), g[tag + '_dictionary_final']) < 2e-5
 
 
+def test_conv_unit_stride_training_step_on_the_matrix_core_path(device):
+  """Stride-1 single-channel convolutional training: the default precision
+  policy sends inference to the bf16x3 MFMA kernels (s >= 32); two training
+  steps against the oracle's train_steps."""
+  import sc_oracle
+  from training import sparse_coding
+  rs = np.random.RandomState(321)
+  k, s_k, pad = 11, 32, 10
+  imgs = np.zeros((4, 1, 40 + 2 * pad, 44 + 2 * pad), np.float32)
+  imgs[:, :, pad:-pad, pad:-pad] = (0.5 * rs.randn(4, 1, 40, 44)).astype(
+      np.float32)
+  K0 = rs.randn(s_k, 1, k, k).astype(np.float32)
+  K0 /= np.sqrt((K0.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[
+      :, None, None, None].astype(np.float32)
+  params = {
+      'mode': 'convolutional', 'num_epochs': 1,
+      'code_inference_algorithm': 'fista', 'strides': (1, 1),
+      'padding': ((pad, pad), (pad, pad)),
+      'inference_param_schedule': {0: {'sparsity_weight': 0.05,
+                                       'num_iters': 4}},
+      'dictionary_update_algorithm': 'sc_steepest_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.005, 'num_iters': 1}}}
+  Kref = torch.from_numpy(K0.copy())
+  sc_oracle.train_steps([torch.from_numpy(imgs[2 * i: 2 * i + 2])
+                         for i in range(2)], Kref, params)
+  K = helpers.to_dev(K0.copy(), device)
+  X = helpers.to_dev(imgs, device)
+  sparse_coding.train_dictionary([X[0:2], X[2:4]], [X[0:2]], K, params)
+  assert helpers.rel_err(K.cpu().numpy(), Kref.numpy()) < 2e-5
+
+
 def test_subspace_step_runs_and_keeps_unit_norm(device):
   from training import sparse_coding
   X = helpers.to_dev(helpers.gaussian_patches(80, 64, 64), device)
