@@ -54,6 +54,19 @@ struct Carver {
   }
 };
 
+// Function attributes (dynamic LDS above 64 KiB) are per device and a process
+// may drive several: true the first time the calling site runs on the current
+// device.  `seen` is a static word of the call site (bit = device ordinal; a
+// concurrent first call only configures twice).
+static inline bool first_use_on_this_device(unsigned long long* seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (*seen & bit) return false;
+  *seen |= bit;
+  return true;
+}
+
 // ---- device helpers -----------------------------------------------------
 // The reference's elementwise arithmetic is un-fused f32 (one rounding per
 // torch op).  These wrappers keep hipcc from contracting a*b+c into an FMA.

@@ -311,12 +311,11 @@ static int launch_synth_unit_k(const float* codes, const float* D,
   const size_t lds = (size_t)kUnitSynChunk *
                      (U::WY * U::WP + K * U::KP) * sizeof(float);
   auto kernel = conv_synth_unit_kernel<K>;
-  static bool configured = false;
-  if (!configured && lds > 64 * 1024) {
+  static unsigned long long configured = 0;
+  if (lds > 64 * 1024 && first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
   }
   const int tiles_x = (int)ceil_div(g.W, kUnitTX);
   const int tiles_y = (int)ceil_div(g.H, kUnitTY);

@@ -635,12 +635,11 @@ static int cx_launch_synth_k(const float* Y, const uint16_t* syn,
   using Dm = CxDims<K>;
   const int tiles_x = (int)ceil_div(g.W, Dm::TW);
   const int tiles_y = (int)ceil_div(g.H, p.th);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(conv_synth_x3_kernel<K>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   hipLaunchKernelGGL(conv_synth_x3_kernel<K>,
                      dim3((unsigned)(tiles_x * tiles_y), (unsigned)g.b),
@@ -669,12 +668,11 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 const ProxParams& pp, hipStream_t st) {
   const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
   const int tiles_u = (int)ceil_div(g.ch, p.ana_rows);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA, FAST>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
   }
   const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
   const int64_t blocks = ceil_div(bands, 8) * 8 * tiles_v;

@@ -881,12 +881,11 @@ template <int NPH, int NP, int MODE>
 static int launch_fused(const FusedParams& P, hipStream_t st) {
   using L = FusedLds<NPH, NP>;
   auto kernel = fused_fista_kernel<NPH, NP, MODE>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
-    configured = true;
   }
   const unsigned grid = (unsigned)ceil_div(P.b, kFP);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), L::total, st, P);
@@ -953,12 +952,11 @@ static void print_stamps(const unsigned long long* host, int num_iters,
 template <int NPH, int MODE, bool STAMP>
 static int launch_lds(FusedParams P, hipStream_t st) {
   auto kernel = fused_fista_lds_kernel<NPH, MODE, STAMP>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsV2Total));
-    configured = true;
   }
   unsigned long long* dev = nullptr;
   if (STAMP) {
@@ -1010,12 +1008,11 @@ static int dispatch_lds(const FusedParams& P, int threshold, hipStream_t st) {
 template <int NPH, int MODE, bool STAMP>
 static int launch_priv(FusedParams P, hipStream_t st) {
   auto kernel = fused_fista_priv_kernel<NPH, MODE, STAMP>;
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, PrivLds<NPH>::total));
-    configured = true;
   }
   unsigned long long* dev = nullptr;
   if (STAMP) {

@@ -234,12 +234,11 @@ extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
   const int k = (int)(n < kLanczosMaxK ? n : kLanczosMaxK);
   const size_t lds =
       ((size_t)k * n + n + k + kLanczosParts * 256) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(lanczos_lambda_max_kernel),
         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    configured = true;
   }
   hipLaunchKernelGGL(lanczos_lambda_max_kernel, dim3(1),
                      dim3(kLanczosThreads), lds,
