@@ -82,13 +82,15 @@ int vtc_abi_version(void);
  * second on the (s, c*kh*kw) flattened kernels. */
 int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
              float* gram, void* stream);
-/* Largest eigenvalue of a symmetric (n,n) matrix, n <= 256, replacing the
+/* Largest eigenvalue of a symmetric (n,n) matrix, n <= 1024, replacing the
  * `torch.symeig(...)[0][-1]` of ista_fista.py:73-74: single-workgroup Lanczos
- * with full re-orthogonalisation + Sturm bisection.  out (device, 2 floats) =
- * [lambda_max, 1/lambda_max].  Larger n: VTC_ERR_UNSUPPORTED (the caller then
- * uses a library eigen-solver). */
+ * with full re-orthogonalisation + Sturm counts.  out (device, 2 floats) =
+ * [lambda_max, 1/lambda_max].  n <= 256 keeps the Krylov basis in LDS and
+ * needs no workspace (NULL, 0); 256 < n <= 1024 keeps it in the workspace.
+ * Larger n: VTC_ERR_UNSUPPORTED (the caller then uses a library eigen-solver). */
+size_t vtc_lambda_max_workspace_bytes(int64_t n);
 int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
-                   void* stream);
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fully-connected inference (row a1) ------------------------------- */
 size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n, int64_t s,

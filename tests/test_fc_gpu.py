@@ -252,3 +252,19 @@ def test_ica_natural_gradient_update(device):
           D.cpu().numpy(),
           g['%s_dictionary_after_%d' % (tag, iters)]) < helpers.REL_TOL_DICT
     assert torch.equal(C, C0)
+
+
+def test_large_patches_use_the_device_eigen_solver(device, plugins):
+  """20x20 patches (n = 400 > 256): the Lipschitz step runs the workspace
+  variant of the device Lanczos kernel, not a library eigen-solver."""
+  import vtc_hip
+  ista_fista = plugins[0]
+  Xn = helpers.gaussian_patches(77, 64, 400)
+  Dn = helpers.unit_rows(78, 500, 400)
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(Xn), torch.from_numpy(Dn),
+                                0.02, 30)
+  assert vtc_hip.LANCZOS_MAX_N >= 400
+  out = ista_fista.run(helpers.to_dev(Xn, device), helpers.to_dev(Dn, device),
+                       0.02, 30, precision='f32')
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(),
+                             helpers.REL_TOL_SHORT, 'n = 400')

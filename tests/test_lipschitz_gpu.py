@@ -13,7 +13,10 @@ def _lambda_max(mat, device):
   lib = vtc_hip.load_library()
   g = helpers.to_dev(mat.astype(np.float32), device)
   out = torch.empty(2, dtype=torch.float32, device=device)
+  ws = vtc_hip.workspace(lib.vtc_lambda_max_workspace_bytes(g.shape[0]),
+                         device)
   vtc_hip.check(lib.vtc_lambda_max(vtc_hip.ptr(g), g.shape[0], vtc_hip.ptr(out),
+                                   vtc_hip.ptr(ws), ws.numel(),
                                    vtc_hip.current_stream(device)), 'lanczos')
   lam, inv = out.tolist()
   return lam, inv
@@ -21,8 +24,12 @@ def _lambda_max(mat, device):
 
 @pytest.mark.parametrize('s,n,seed', [(1024, 256, 1), (512, 256, 51),
                                       (64, 64, 11), (6, 16, 21), (256, 256, 3),
-                                      (4096, 256, 5), (300, 200, 9)])
+                                      (4096, 256, 5), (300, 200, 9),
+                                      (800, 400, 13), (2048, 1024, 17),
+                                      (300, 576, 19)])
 def test_dictionary_grams(device, s, n, seed):
+  """n <= 256: Krylov basis in LDS; 256 < n <= 1024 (20x20, 24x24, 32x32
+  patches; the last case is rank deficient): basis in a global workspace."""
   D = helpers.unit_rows(seed, s, n).astype(np.float64)
   gram = D.T @ D
   ref = np.linalg.eigvalsh(gram)[-1]

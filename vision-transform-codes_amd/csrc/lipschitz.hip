@@ -217,21 +217,169 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
   }
 }
 
+// ---------------------------------------------------------------- n > 256
+// Same iteration for 256 < n <= 1024 (e.g. 20x20 or 32x32 patches): one
+// thread per vector component, the Krylov basis (k x n floats, up to 512 KiB)
+// in a global workspace instead of LDS.  ~2 ms at n = 1024, once per call.
+constexpr int kLanczosLargeN = 1024;
+
+__device__ __forceinline__ double block_sum_all(double v, double* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double total = 0.0;
+  for (int w = 0; w < kLanczosThreads / 64; ++w) total += red[w];
+  return total;
+}
+
+__global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
+    const float* __restrict__ G, int n, int k, float* __restrict__ V,
+    float* __restrict__ out) {
+  __shared__ float vcur[kLanczosLargeN];
+  __shared__ float wl[kLanczosLargeN];
+  __shared__ float coef[kLanczosMaxK];
+  __shared__ double red[kLanczosThreads / 64];
+  __shared__ double alpha[kLanczosMaxK];
+  __shared__ double beta[kLanczosMaxK];
+  __shared__ int steps_done;
+  __shared__ int stop_flag;
+  __shared__ double last_ritz;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const bool on = t < n;
+
+  float v = 0.f;
+  if (on) {
+    unsigned x = (unsigned)t * 2654435761u + 12345u;
+    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+    v = 0.5f + (float)(x & 0xffff) / 65536.f;
+  }
+  const double nrm = sqrt(block_sum_all((double)v * v, red));
+  v = (float)(v / nrm);
+  float v_prev = 0.f;
+  double beta_prev = 0.0;
+  if (t == 0) {
+    steps_done = k;
+    stop_flag = 0;
+    last_ritz = -1.0;
+  }
+  double tscale = 0.0;
+  __syncthreads();
+
+  for (int j = 0; j < k; ++j) {
+    if (on) {
+      V[(size_t)j * n + t] = v;
+      vcur[t] = v;
+    }
+    __syncthreads();
+    // w = G v: G symmetric, so "column" t is read along rows, coalesced
+    float w = 0.f;
+    if (on) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int i = 0;
+      for (; i + 3 < n; i += 4) {
+        a0 = fmaf(G[(size_t)(i + 0) * n + t], vcur[i + 0], a0);
+        a1 = fmaf(G[(size_t)(i + 1) * n + t], vcur[i + 1], a1);
+        a2 = fmaf(G[(size_t)(i + 2) * n + t], vcur[i + 2], a2);
+        a3 = fmaf(G[(size_t)(i + 3) * n + t], vcur[i + 3], a3);
+      }
+      for (; i < n; ++i) a0 = fmaf(G[(size_t)i * n + t], vcur[i], a0);
+      w = (a0 + a1) + (a2 + a3);
+    }
+    const double a = block_sum_all(on ? (double)w * v : 0.0, red);
+    if (on) {
+      w = w - (float)a * v - (float)beta_prev * v_prev;
+      wl[t] = w;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // full re-orthogonalisation against V[0..j] (this block wrote them)
+    for (int i = wave; i <= j; i += kLanczosThreads / 64) {
+      float p = 0.f;
+      for (int c = lane; c < n; c += 64) p = fmaf(V[(size_t)i * n + c], wl[c], p);
+      p = wave_sum(p);
+      if (lane == 0) coef[i] = p;
+    }
+    __syncthreads();
+    if (on) {
+      float corr = 0.f;
+      for (int i = 0; i <= j; ++i) corr = fmaf(coef[i], V[(size_t)i * n + t], corr);
+      w -= corr;
+    }
+    const double b = sqrt(block_sum_all(on ? (double)w * w : 0.0, red));
+    if (t == 0) {
+      alpha[j] = a;
+      beta[j] = b;
+    }
+    tscale = fmax(tscale, fmax(fabs(a), b));
+    if (!(b > 1e-5 * tscale)) {
+      if (t == 0) steps_done = j + 1;
+      break;
+    }
+    if ((j & 7) == 7) {
+      __syncthreads();
+      if (wave == 0) {
+        const double ritz = tridiagonal_lambda_max(alpha, beta, j + 1);
+        if (t == 0) {
+          stop_flag = (last_ritz > 0.0 &&
+                       fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
+          last_ritz = ritz;
+        }
+      }
+      __syncthreads();
+      if (stop_flag) {
+        if (t == 0) steps_done = j + 1;
+        break;
+      }
+    }
+    v_prev = v;
+    v = (float)(w / b);
+    beta_prev = b;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const double lambda = tridiagonal_lambda_max(alpha, beta, steps_done);
+    const float lf = (float)lambda;
+    if (t == 0) {
+      out[0] = lf;
+      out[1] = 1.f / lf;
+    }
+  }
+}
+
 }  // namespace vtc
 
 using namespace vtc;
 
+extern "C" size_t vtc_lambda_max_workspace_bytes(int64_t n) {
+  if (n <= kLanczosMaxN || n > kLanczosLargeN) return 256;
+  return align_up((size_t)kLanczosMaxK * n * sizeof(float), 256);
+}
+
 // out: 2 floats on the device: [lambda_max, 1/lambda_max]
 extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
+                              void* workspace, size_t workspace_bytes,
                               void* stream) {
   VTC_REQUIRE(symmetric && out, "vtc_lambda_max: null pointer");
   VTC_REQUIRE(n > 0, "vtc_lambda_max: bad size");
-  if (n > kLanczosMaxN) {
+  if (n > kLanczosLargeN) {
     set_error("vtc_lambda_max: n = %lld exceeds the single-workgroup Lanczos "
-              "limit of %d", (long long)n, kLanczosMaxN);
+              "limit of %d", (long long)n, kLanczosLargeN);
     return VTC_ERR_UNSUPPORTED;
   }
   const int k = (int)(n < kLanczosMaxK ? n : kLanczosMaxK);
+  if (n > kLanczosMaxN) {
+    if (!workspace || workspace_bytes < vtc_lambda_max_workspace_bytes(n)) {
+      set_error("vtc_lambda_max: workspace too small");
+      return VTC_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(lanczos_large_kernel, dim3(1), dim3(kLanczosThreads), 0,
+                       as_stream(stream), symmetric, (int)n, k,
+                       static_cast<float*>(workspace), out);
+    VTC_LAUNCH_CHECK();
+    return VTC_OK;
+  }
   const size_t lds =
       ((size_t)k * n + n + k + kLanczosParts * 256) * sizeof(float);
   static unsigned long long configured = 0;

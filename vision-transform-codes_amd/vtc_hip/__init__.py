@@ -55,7 +55,8 @@ SIGNATURES = {
     'vtc_last_error': (ctypes.c_char_p, []),
     'vtc_abi_version': (_i32, []),
     'vtc_gram': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
-    'vtc_lambda_max': (_i32, [_vp, _i64, _vp, _vp]),
+    'vtc_lambda_max_workspace_bytes': (_sz, [_i64]),
+    'vtc_lambda_max': (_i32, [_vp, _i64, _vp, _vp, _sz, _vp]),
     'vtc_fc_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i32]),
     'vtc_fc_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                  _f32, _i32, _i32, _i32, _f32, _i32, _vp, _sz,
@@ -254,14 +255,14 @@ def gram(matrix, transpose_a):
   return out
 
 
-LANCZOS_MAX_N = 256
+LANCZOS_MAX_N = 1024
 _use_device_eigensolver = os.environ.get('VTC_EIGEN', 'lanczos') != 'library'
 
 
 def stepsize_from_gram(gram_matrix, dictionary_for_message):
   """eta = 1 / lambda_max(gram) as a Python float.
 
-  n <= 256: vtc_lambda_max (one small HIP kernel: Lanczos + bisection).
+  n <= 1024: vtc_lambda_max (one small HIP kernel: Lanczos + Sturm counts).
   Otherwise torch.linalg.eigvalsh, the successor of the torch.symeig the
   reference calls (removed in torch >= 2).  Mirrors the reference's error
   path: on failure print the kernel norms and raise a bare RuntimeError
@@ -271,7 +272,10 @@ def stepsize_from_gram(gram_matrix, dictionary_for_message):
     if _use_device_eigensolver and n <= LANCZOS_MAX_N:
       lib = load_library()
       out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
-      check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out),
+      ws = workspace(lib.vtc_lambda_max_workspace_bytes(n),
+                     gram_matrix.device)
+      check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out), ptr(ws),
+                               ws.numel(),
                                current_stream(gram_matrix.device)),
             'vtc_lambda_max')
       lipschitz_constant, stepsize = [float(v) for v in out.tolist()]
