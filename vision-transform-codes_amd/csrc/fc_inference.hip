@@ -144,14 +144,19 @@ static int run_generic(const float* images, const float* dictionary,
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     // G = R D^T : A = R (b,n) k-contiguous, B = D (s,n) = [N][K]
-    if (x3) {
+    const bool wide_ok = s % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(codes) & 15) == 0;
+    if (x3 || wide_ok) {
       // 16-byte, pipelined epilogue (epi_prox.h); in ISTA Y and the codes are
       // one buffer and both stores carry the same value
       EpiGroupProx<1, true> e2{Y, codes, s, eta, cutoff,
                                fista ? betas[k] : 0.f, fista ? 1 : 0,
                                eps >= 0.f ? delta_sum : nullptr, 0.0,
                                threshold};
-      rc = launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st);
+      rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st)
+              : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
+                                            e2, st);
     } else {
       EpiProx e2{Y, codes, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
                  fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0};

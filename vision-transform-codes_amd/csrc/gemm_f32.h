@@ -15,6 +15,8 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace vtc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,6 +26,44 @@ constexpr int kGemmBN = 128;
 constexpr int kGemmBK = 16;
 constexpr int kGemmPitch = 132;
 constexpr int kGemmThreads = 256;
+
+// An epilogue that declares `static constexpr bool kWholeTile` receives each
+// 32x32 accumulator tile at once through
+//   tile(row0, col0, lane, acc, rows, cols)
+// (lane l holds column col0 + (l & 31), register r holds row
+//  row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)), every lane of the wave
+// calling it, so it may combine columns with lane shuffles.
+template <class E, class = void>
+struct epi_whole_tile : std::false_type {};
+template <class E>
+struct epi_whole_tile<E, std::void_t<decltype(E::kWholeTile)>>
+    : std::true_type {};
+// A whole-tile epilogue that also declares `kPrefetch` (floats per lane it
+// wants to read per tile) is run as a pipeline over the wave's four tiles:
+//   ctx = begin(m0, M)                 once per block
+//   load(ctx, row_in_block, col0, lane, N, buf)     issue the tile's reads
+//   finish(ctx, row_in_block, col0, lane, N, acc, buf, scratch)   compute and
+//       store; `scratch` = 8 KiB of LDS private to the wave
+// load(tile 0) is issued before the K loop, load(t+1) before finish(t): a
+// store orders later loads of the same array behind it, so without this each
+// tile would pay a full memory round trip.
+template <class E, class = void>
+struct epi_prefetch : std::false_type {};
+template <class E>
+struct epi_prefetch<E, std::void_t<decltype(E::kPrefetch)>> : std::true_type {};
+template <class E, bool = epi_prefetch<E>::value>
+struct epi_prefetch_floats { static constexpr int value = 1; };
+template <class E>
+struct epi_prefetch_floats<E, true> {
+  static constexpr int value = E::kPrefetch;
+};
+
+typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kX3BM = 128, kX3BN = 128, kX3BK = 32;
+constexpr int kX3TileBytes = 128 * 64;   // one operand part: 128 rows x 64 B
 
 // C[M,N] = opA * opB over k in [z*k_chunk, min(K, (z+1)*k_chunk)), z=blockIdx.y
 //   A_KC: A is stored [M][K] (k contiguous, leading dim lda); else [K][M].
@@ -125,6 +165,17 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // pipelined whole-tile epilogue (see the traits above): the first tile's
+  // reads are issued before the K loop
+  constexpr bool kPipe = epi_prefetch<Epi>::value;
+  float pre0[epi_prefetch_floats<Epi>::value],
+      pre1[epi_prefetch_floats<Epi>::value];
+  auto ctx = [&] {
+    if constexpr (kPipe) return epi.begin(m0, g.M); else return 0;
+  }();
+  if constexpr (kPipe)
+    epi.load(ctx, wm * 64, n0 + wn * 64, lane, g.N, pre0);
+
   float4 ra[2], rb[2];
   if (nk > 0) {
     stage_load<A_KC>(g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid, ra);
@@ -163,6 +214,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
     cur ^= 1;
   }
 
+  if constexpr (kPipe) {
+    // the operand tiles are dead after the K loop (last barrier above): two
+    // waves stage their accumulator tiles through As, two through Bs
+    float* scratch = (wave < 2 ? &As[0][0][0] : &Bs[0][0][0]) +
+                     (wave & 1) * 2048;
+    const int r0 = wm * 64;
+    const int64_t c0 = n0 + wn * 64;
+    epi.load(ctx, r0, c0 + 32, lane, g.N, pre1);
+    epi.finish(ctx, r0, c0, lane, g.N, acc[0][0], pre0, scratch);
+    epi.load(ctx, r0 + 32, c0, lane, g.N, pre0);
+    epi.finish(ctx, r0, c0 + 32, lane, g.N, acc[0][1], pre1, scratch);
+    epi.load(ctx, r0 + 32, c0 + 32, lane, g.N, pre1);
+    epi.finish(ctx, r0 + 32, c0, lane, g.N, acc[1][0], pre0, scratch);
+    epi.finish(ctx, r0 + 32, c0 + 32, lane, g.N, acc[1][1], pre1, scratch);
+    epi.block_end();
+    return;
+  }
   // C/D layout of the 32x32 MFMA: column = lane & 31,
   // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #pragma unroll

@@ -20,47 +20,7 @@
 #include "common.h"
 #include "gemm_f32.h"
 
-#include <type_traits>
-
 namespace vtc {
-
-// An epilogue that declares `static constexpr bool kWholeTile` receives each
-// 32x32 accumulator tile at once through
-//   tile(row0, col0, lane, acc, rows, cols)
-// (lane l holds column col0 + (l & 31), register r holds row
-//  row0 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)), every lane of the wave
-// calling it, so it may combine columns with lane shuffles.
-template <class E, class = void>
-struct epi_whole_tile : std::false_type {};
-template <class E>
-struct epi_whole_tile<E, std::void_t<decltype(E::kWholeTile)>>
-    : std::true_type {};
-// A whole-tile epilogue that also declares `kPrefetch` (floats per lane it
-// wants to read per tile) is run as a pipeline over the wave's four tiles:
-//   ctx = begin(m0, M)                 once per block
-//   load(ctx, row_in_block, col0, lane, N, buf)     issue the tile's reads
-//   finish(ctx, row_in_block, col0, lane, N, acc, buf, scratch)   compute and
-//       store; `scratch` = 8 KiB of LDS private to the wave
-// load(tile 0) is issued before the K loop, load(t+1) before finish(t): a
-// store orders later loads of the same array behind it, so without this each
-// tile would pay a full memory round trip.
-template <class E, class = void>
-struct epi_prefetch : std::false_type {};
-template <class E>
-struct epi_prefetch<E, std::void_t<decltype(E::kPrefetch)>> : std::true_type {};
-template <class E, bool = epi_prefetch<E>::value>
-struct epi_prefetch_floats { static constexpr int value = 1; };
-template <class E>
-struct epi_prefetch_floats<E, true> {
-  static constexpr int value = E::kPrefetch;
-};
-
-typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kX3BM = 128, kX3BN = 128, kX3BK = 32;
-constexpr int kX3TileBytes = 128 * 64;   // one operand part: 128 rows x 64 B
 
 struct GemmX3Args {
   const float* A;

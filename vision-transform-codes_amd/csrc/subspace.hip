@@ -35,13 +35,16 @@ struct EpiGradStep {  // Y <- Y - eta * g
   __device__ __forceinline__ void block_end() const {}
 };
 
+// G = R Dg^T with the gradient step and the group proximal step in the
+// epilogue, on the bf16x3 tiles or the exact-f32 ones
 template <int M>
-static int launch_grad_prox_x3(const float* R, const float* Dg, float* Y,
-                               float* C, int64_t b, int64_t slots, int64_t n,
-                               float eta, float cutoff, float beta, int fista,
-                               double* delta_sum, hipStream_t st) {
+static int launch_grad_prox(bool x3, const float* R, const float* Dg, float* Y,
+                            float* C, int64_t b, int64_t slots, int64_t n,
+                            float eta, float cutoff, float beta, int fista,
+                            double* delta_sum, hipStream_t st) {
   EpiGroupProx<M> e{Y, C, slots, eta, cutoff, beta, fista, delta_sum, 0.0, 0};
-  return launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st);
+  return x3 ? launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st)
+            : launch_gemm_f32<true, true>(R, n, Dg, n, b, slots, n, 1, e, st);
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ D,
@@ -405,10 +408,14 @@ extern "C" int vtc_subspace_ista_fista(
     const float beta_k = fista ? betas[k] : 0.f;
     double* dsum = eps >= 0.f ? delta_sum : nullptr;
     bool fused_prox = false;
-    if (x3) {
+    // 16-byte epilogue accesses: slots a multiple of 4, 16-byte aligned state
+    const bool wide_ok = slots % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(grouped_codes) & 15) == 0;
+    if (wide_ok) {
 #define VTC_FUSED_PROX(MM)                                                  \
   case MM:                                                                  \
-    rc = launch_grad_prox_x3<MM>(R, grouped_dictionary, Y, grouped_codes,   \
+    rc = launch_grad_prox<MM>(x3, R, grouped_dictionary, Y, grouped_codes,  \
                                  b, slots, n, eta, cutoff, beta_k,          \
                                  fista ? 1 : 0, dsum, st);                  \
     fused_prox = true;                                                      \
