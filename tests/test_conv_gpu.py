@@ -279,3 +279,12 @@ def test_full_size_properties(device, plugins):
   helpers.assert_codes_match(both[:1].cpu().numpy(), exact.cpu().numpy(),
                              5e-5, 'conv bf16x3 vs f32 path',
                              max_flip_mag=5e-6)
+
+
+def test_empty_batch(device, plugins):
+  conv = plugins[0]
+  D = helpers.to_dev(np.ones((4, 1, 8, 8), np.float32) / 8.0, device)
+  for precision in ('f32', 'auto'):
+    out = conv.run(torch.zeros(0, 1, 24, 24, device=device), D, (4, 4), None,
+                   0.05, 3, precision=precision, stepsize=0.1)
+    assert tuple(out.shape) == (0, 4, 5, 5)

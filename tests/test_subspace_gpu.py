@@ -201,3 +201,11 @@ def test_full_size_properties(device, plugins):
   helpers.assert_codes_match(full[:512].cpu().numpy(), exact.cpu().numpy(),
                              5e-5, 'subspace bf16x3 vs f32 path',
                              max_flip_mag=5e-6)
+
+
+def test_empty_batch(device, plugins):
+  sub = plugins[0]
+  D = helpers.to_dev(helpers.unit_rows(3, 16, 32), device)
+  groups = [list(range(4 * g, 4 * g + 4)) for g in range(4)]
+  out = sub.run(torch.zeros(0, 32, device=device), D, groups, 0.05, 3)
+  assert tuple(out.shape) == (0, 16)

@@ -507,7 +507,7 @@ extern "C" int vtc_conv_ista_fista(
     float stepsize, float sparsity_weight, int num_iters, int variant,
     int threshold, float early_stopping_epsilon, int precision,
     void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
-  VTC_REQUIRE(images_padded && dictionary && codes,
+  VTC_REQUIRE((geom && geom->b == 0) || (images_padded && dictionary && codes),
               "vtc_conv_ista_fista: null pointer");
   VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
               "vtc_conv_ista_fista: precision must be VTC_F32 or VTC_BF16X3");

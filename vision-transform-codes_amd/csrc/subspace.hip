@@ -289,10 +289,10 @@ extern "C" int vtc_group_gather_cols(const float* codes, const int32_t* index,
                                      const uint8_t* valid,
                                      float* grouped_codes, int64_t b,
                                      int64_t s, int64_t slots, void* stream) {
+  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_gather_cols: sizes");
+  if (b == 0) return VTC_OK;   // empty tensors have null data pointers
   VTC_REQUIRE(codes && index && valid && grouped_codes,
               "vtc_group_gather_cols: null pointer");
-  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_gather_cols: sizes");
-  if (b == 0) return VTC_OK;
   hipLaunchKernelGGL(gather_cols_kernel, dim3(flat_grid(b * slots)), dim3(256),
                      0, as_stream(stream), codes, index, valid, grouped_codes,
                      b, s, slots);
@@ -305,10 +305,10 @@ extern "C" int vtc_group_scatter_add(const float* grouped_codes,
                                      const int32_t* atom_slots, float* codes,
                                      int64_t b, int64_t s, int64_t slots,
                                      void* stream) {
+  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_scatter_add: sizes");
+  if (b == 0) return VTC_OK;   // empty tensors have null data pointers
   VTC_REQUIRE(grouped_codes && atom_ptr && atom_slots && codes,
               "vtc_group_scatter_add: null pointer");
-  VTC_REQUIRE(b >= 0 && s > 0 && slots > 0, "vtc_group_scatter_add: sizes");
-  if (b == 0) return VTC_OK;
   hipLaunchKernelGGL(scatter_add_kernel, dim3(flat_grid(b * s)), dim3(256), 0,
                      as_stream(stream), grouped_codes, atom_ptr, atom_slots,
                      codes, b, s, slots);
@@ -329,7 +329,7 @@ extern "C" int vtc_subspace_ista_fista(
     int64_t groups, int64_t m, float stepsize, float sparsity_weight,
     int num_iters, int variant, float early_stopping_epsilon, int precision,
     void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
-  VTC_REQUIRE(images && grouped_dictionary && grouped_codes,
+  VTC_REQUIRE(b == 0 || (images && grouped_dictionary && grouped_codes),
               "vtc_subspace_ista_fista: null pointer");
   VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
               "vtc_subspace_ista_fista: precision must be VTC_F32 or "
