@@ -197,11 +197,14 @@ int vtc_fc_dict_apply(float* dictionary, const float* grad_sum,
 /* ---- dictionary update, convolutional (rows a8, a9) --------------------- */
 size_t vtc_conv_dict_gradient_workspace_bytes(const vtc_conv_geometry* g);
 /* grad_sum (s,c,kh,kw) = sum_{b,p,q} codes[b,s,p,q] * r[b,c,p*sv+dy,q*sh+dx],
- * r = mask * (synthesis(codes) - images_padded): NOT divided by b. */
+ * r = mask * (synthesis(codes) - images_padded): NOT divided by b.
+ * precision: VTC_F32 (direct kernels) or VTC_BF16X3 (residual and gradient as
+ * bf16 hi/lo split MFMA contractions; needs vtc_conv_x3_supported). */
 int vtc_conv_dict_gradient(const float* images_padded, const float* dictionary,
                            const float* codes, float* grad_sum,
-                           const vtc_conv_geometry* g, void* workspace,
-                           size_t workspace_bytes, void* stream);
+                           const vtc_conv_geometry* g, int precision,
+                           void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* g = grad_sum/global_batch; g /= (h + lowest_code_val) iff hessian given;
  * g *= ||D||_F/||g||_F; D -= stepsize*g; per-kernel l2 normalise iff normalize.
  * scratch: s*kernel_elems floats of device memory. */

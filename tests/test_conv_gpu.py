@@ -288,3 +288,42 @@ def test_empty_batch(device, plugins):
     out = conv.run(torch.zeros(0, 1, 24, 24, device=device), D, (4, 4), None,
                    0.05, 3, precision=precision, stepsize=0.1)
     assert tuple(out.shape) == (0, 4, 5, 5)
+
+
+@pytest.mark.parametrize('k,s,height,width', [(11, 32, 50, 77), (11, 130, 36, 40),
+                                              (5, 40, 41, 70), (8, 64, 33, 66),
+                                              (16, 33, 40, 48)])
+def test_bf16x3_dictionary_gradient(device, plugins, k, s, height, width):
+  """Convolutional dictionary updates with at least 32 kernels of a stride-1
+  single-channel geometry take the matrix-core route (residual and gradient
+  as split-bf16 contractions, conv_x3.h): both update rules against the
+  oracle at the f32 route's tolerance (5e-6 relative on the dictionary), more
+  than 128 kernels, kernel counts that are not multiples of 32, tile-ragged
+  code maps."""
+  _, steepest, cheapquad = plugins
+  imgs, D, padding = _conv_case(3000 + k + s, k, s, height, width)
+  rs = np.random.RandomState(k * s)
+  ch, cw = height + k - 1, width + k - 1
+  codes = (rs.randn(2, s, ch, cw) * (rs.rand(2, s, ch, cw) < 0.2)).astype(
+      np.float32) * 0.05
+  hd = (0.01 + 0.05 * rs.rand(s)).astype(np.float32)
+  X, C = helpers.to_dev(imgs, device), helpers.to_dev(codes, device)
+  refD = torch.from_numpy(D.copy())
+  sc_oracle.conv_steepest_descent(torch.from_numpy(imgs), refD,
+                                  torch.from_numpy(codes), (1, 1), padding,
+                                  stepsize=0.005)
+  Dg = helpers.to_dev(D.copy(), device)
+  steepest.run(X, Dg, C, (1, 1), padding, stepsize=0.005)
+  assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
+  refD = torch.from_numpy(D.copy())
+  sc_oracle.conv_cheap_quadratic_descent(
+      torch.from_numpy(imgs), refD, torch.from_numpy(codes),
+      torch.from_numpy(hd), (1, 1), padding, stepsize=0.005)
+  Dg = helpers.to_dev(D.copy(), device)
+  cheapquad.run(X, Dg, C, helpers.to_dev(hd, device), (1, 1), padding,
+                stepsize=0.005)
+  assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
+  again = helpers.to_dev(D.copy(), device)
+  cheapquad.run(X, again, C, helpers.to_dev(hd, device), (1, 1), padding,
+                stepsize=0.005)
+  assert torch.equal(again, Dg)                 # fixed summation order

@@ -665,23 +665,40 @@ extern "C" size_t vtc_conv_dict_gradient_workspace_bytes(
   const AnaPlan ap = plan_analysis(g);
   const int64_t tiles =
       g.b * ceil_div(g.ch, ap.tp) * ceil_div(g.cw, ap.tq);
+  size_t slab_count = (size_t)grad_blocks(tiles);
+  size_t extra = 0;
+  CxPlan xp;
+  if (cx_plan(g, &xp)) {                            // bf16x3 route
+    if ((size_t)cx_grad_blocks(g) > slab_count) slab_count = cx_grad_blocks(g);
+    extra = cx_image_bytes(xp);
+  }
   return align_up((size_t)g.b * g.c * g.H * g.W * sizeof(float), 256) +
-         align_up((size_t)grad_blocks(tiles) * g.s * g.c * g.kh * g.kw *
-                      sizeof(float), 256);
+         align_up(slab_count * g.s * g.c * g.kh * g.kw * sizeof(float), 256) +
+         extra;
 }
 
 extern "C" int vtc_conv_dict_gradient(const float* images_padded,
                                       const float* dictionary,
                                       const float* codes, float* grad_sum,
                                       const vtc_conv_geometry* geom,
-                                      void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+                                      int precision, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
   VTC_REQUIRE(images_padded && dictionary && codes && grad_sum,
               "vtc_conv_dict_gradient: null pointer");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
+              "vtc_conv_dict_gradient: precision must be VTC_F32 or "
+              "VTC_BF16X3");
   ConvGeo g;
   int rc = make_geo(geom, &g);
   if (rc != VTC_OK) return rc;
   VTC_REQUIRE(g.b > 0, "vtc_conv_dict_gradient: empty batch");
+  CxPlan xp;
+  const bool x3 = (precision == VTC_BF16X3);
+  if (x3 && !cx_plan(g, &xp)) {
+    set_error("vtc_conv_dict_gradient: no bf16x3 route for this geometry "
+              "(see vtc_conv_x3_supported)");
+    return VTC_ERR_UNSUPPORTED;
+  }
   if (!workspace ||
       workspace_bytes < vtc_conv_dict_gradient_workspace_bytes(geom)) {
     set_error("vtc_conv_dict_gradient: workspace too small");
@@ -696,6 +713,23 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
   const int64_t dict_elems = (int64_t)g.s * g.c * g.kh * g.kw;
   Carver ws(workspace);
   float* residual = ws.take<float>((size_t)g.b * g.c * g.H * g.W);
+  if (x3) {
+    // residual and gradient on the matrix cores (conv_x3.h); the slab sum and
+    // everything after it are the same as on the f32 route
+    const int xblocks = cx_grad_blocks(g);
+    float* xslabs = ws.take<float>((size_t)(xblocks > blocks ? xblocks
+                                                              : blocks) *
+                                   dict_elems);
+    uint16_t* syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
+    uint16_t* ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
+    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
+    if (rc != VTC_OK) return rc;
+    rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp, st);
+    if (rc != VTC_OK) return rc;
+    rc = cx_launch_grad(residual, codes, xslabs, g, xp, st);
+    if (rc != VTC_OK) return rc;
+    return launch_slab_reduce(xslabs, xblocks, dict_elems, grad_sum, st);
+  }
   float* slabs = ws.take<float>((size_t)blocks * dict_elems);
   rc = launch_synthesis(codes, dictionary, images_padded, residual, g, st);
   if (rc != VTC_OK) return rc;

@@ -34,6 +34,7 @@
 namespace vtc {
 
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int cx_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCxStrip = 64;       // code columns per wave unit (2 MFMA tiles)
 constexpr int kCxSynWaves = 8;
@@ -518,6 +519,125 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   }
 }
 
+// ---------------------------------------------- dictionary gradient (a8/a9)
+// dD[s, dy, dx] = sum_{image, u, v} C[s, u, v] * r[u + dy, v + dx]
+// (dict_update_rules/convolutional/sc_steepest_descent.py:60-65) as a
+// contraction over code positions: M = atoms, N = taps (an accumulator tile =
+// 2 tap rows x 16 dx), K = 16 consecutive code columns of one code row.
+//   A: a lane holds 8 consecutive codes of one atom, straight from HBM (two
+//      16-byte buffer loads) and split to bf16 hi / lo in registers;
+//   B: a lane holds 8 consecutive residual pixels of window row u + dy,
+//      starting at column v + dx: the same unaligned 16-byte LDS read as in the
+//      analysis kernel.
+// Blocks are persistent: each walks its share of (image, 8 code rows, 64 code
+// columns) items with the partial dD of 4 x 32 atoms in registers (one atom
+// tile per wave), writes one slab at the end; the slabs are summed in a fixed
+// order.  Atoms beyond 128 are handled by further passes (grid.y).
+constexpr int kCxGradRows = 8;
+
+template <int K>
+__global__ __launch_bounds__(256) void conv_grad_x3_kernel(
+    const float* __restrict__ R, const float* __restrict__ C,
+    float* __restrict__ slabs, ConvGeo g, int tiles_v, int tiles_u,
+    int64_t items) {
+  constexpr int NT = (K + 1) / 2;                  // accumulator tiles (2 dy each)
+  constexpr int WROWS = kCxGradRows + 2 * NT;      // window rows incl. padding
+  __shared__ __attribute__((aligned(16))) uint16_t Rh[WROWS * kCxAnaPitch];
+  __shared__ __attribute__((aligned(16))) uint16_t Rl[WROWS * kCxAnaPitch];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int atom0 = (blockIdx.y * 4 + wave) * 32;  // this wave's atom tile
+  const int atom = atom0 + l31;
+  const bool atom_ok = atom < g.s;
+  const int64_t map = (int64_t)g.ch * g.cw;
+  const unsigned map4 = (unsigned)(map * 4);
+  const int dyi = l31 >> 4, dx = l31 & 15;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+  for (int64_t item = blockIdx.x; item < items; item += gridDim.x) {
+    const int tile_v = (int)(item % tiles_v);
+    const int tile_u = (int)((item / tiles_v) % tiles_u);
+    const int64_t img = item / ((int64_t)tiles_v * tiles_u);
+    const int u0 = tile_u * kCxGradRows, v0 = tile_v * kCxStrip;
+    __syncthreads();                               // window of the last item
+    {
+      const float* Rimg = R + img * g.H * (int64_t)g.W;
+      for (int e = tid; e < WROWS * kCxAnaPitch; e += 256) {
+        const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
+        const int y = u0 + ry, x = v0 + rx;
+        const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
+        const __bf16 h = (__bf16)v;
+        Rh[e] = cx_bits(h);
+        Rl[e] = cx_bits((__bf16)(v - (float)h));
+      }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(C + img * g.s * map), 0, (int)((int64_t)g.s * map * 4),
+        0x00020000);
+    for (int lu = 0; lu < kCxGradRows; ++lu) {
+      const int u = u0 + lu;
+      if (u >= g.ch) break;                        // whole block
+#pragma unroll
+      for (int ks = 0; ks < kCxStrip / 16; ++ks) {
+        const int v = v0 + 16 * ks + 8 * half;     // first of this lane's 8
+        float a[8];
+        {
+          const unsigned off =
+              atom_ok ? (unsigned)atom * map4 + (unsigned)(u * g.cw + v) * 4u
+                      : 0x80000000u;
+          const cx_u32x4 lo4 =
+              __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0);
+          const cx_u32x4 hi4 =
+              __builtin_amdgcn_raw_buffer_load_b128(crs, off, 16, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            a[i] = (v + i < g.cw) ? __uint_as_float(lo4[i]) : 0.f;
+            a[4 + i] = (v + 4 + i < g.cw) ? __uint_as_float(hi4[i]) : 0.f;
+          }
+        }
+        cx_bf16x8 ah, al;
+        cx_split8(a, ah, al);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int off = (lu + 2 * nt + dyi) * kCxAnaPitch + 16 * ks +
+                          8 * half + dx;
+          const CxUnaligned16 h =
+              *reinterpret_cast<const CxUnaligned16*>(Rh + off);
+          const CxUnaligned16 l =
+              *reinterpret_cast<const CxUnaligned16*>(Rl + off);
+          const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, h);
+          const cx_bf16x8 bl = __builtin_bit_cast(cx_bf16x8, l);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt],
+                                                            0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt],
+                                                            0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt],
+                                                            0, 0, 0);
+        }
+      }
+    }
+  }
+  // this block's partial sums: slab[blockIdx.x][atom][tap]
+  float* slab = slabs + (int64_t)blockIdx.x * g.s * (K * K);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int dy = 2 * nt + dyi;
+    if (dy >= K || dx >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a_out = atom0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (a_out < g.s) slab[(int64_t)a_out * (K * K) + dy * K + dx] = acc[nt][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ host
 struct CxPlan {
   int k, s16, slots, AC, chunks;
@@ -696,6 +816,40 @@ static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
                 : cx_launch_analysis_m<2, false>(R, ana, Y, C, g, p, pp, st);
   return fast ? cx_launch_analysis_m<1, true>(R, ana, Y, C, g, p, pp, st)
               : cx_launch_analysis_m<1, false>(R, ana, Y, C, g, p, pp, st);
+}
+
+// blocks of the gradient kernel (and slabs of its output)
+static int cx_grad_blocks(const ConvGeo& g) {
+  const int64_t items = ceil_div(g.cw, kCxStrip) *
+                        ceil_div(g.ch, kCxGradRows) * g.b;
+  const int64_t want = (int64_t)4 * cx_compute_units();
+  return (int)(items < want ? items : want);
+}
+
+template <int K>
+static int cx_launch_grad_k(const float* R, const float* C, float* slabs,
+                            const ConvGeo& g, hipStream_t st) {
+  const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
+  const int tiles_u = (int)ceil_div(g.ch, kCxGradRows);
+  const int64_t items = (int64_t)tiles_v * tiles_u * g.b;
+  hipLaunchKernelGGL(conv_grad_x3_kernel<K>,
+                     dim3((unsigned)cx_grad_blocks(g),
+                          (unsigned)ceil_div(g.s, 128)),
+                     dim3(256), 0, st, R, C, slabs, g, tiles_v, tiles_u, items);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+static int cx_launch_grad(const float* R, const float* C, float* slabs,
+                          const ConvGeo& g, const CxPlan& p, hipStream_t st) {
+  switch (p.k) {
+    case 5: return cx_launch_grad_k<5>(R, C, slabs, g, st);
+    case 8: return cx_launch_grad_k<8>(R, C, slabs, g, st);
+    case 11: return cx_launch_grad_k<11>(R, C, slabs, g, st);
+    case 16: return cx_launch_grad_k<16>(R, C, slabs, g, st);
+  }
+  set_error("conv bf16x3: kernel size not instantiated");
+  return VTC_ERR_UNSUPPORTED;
 }
 
 }  // namespace vtc

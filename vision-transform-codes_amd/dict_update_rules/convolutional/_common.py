@@ -37,11 +37,22 @@ def descend(images_padded, dictionary, codes, kernel_stride, padding_dims,
   grad_sum = torch.empty_like(dictionary)
   scratch = torch.empty_like(dictionary)
   total_batch = parallel.global_batch(geom.b, device)
+  # precision policy of the process (vtc_hip.set_default_precision): 'auto'
+  # takes the bf16x3 matrix-core route where the inference plugin does (one
+  # channel, stride 1, square kernels 5/8/11/16, at least 32 kernels)
+  name = vtc_hip.get_default_precision()
+  if name == 'auto':
+    name = 'bf16x3' if (geom.s >= 32 and lib.vtc_conv_x3_supported(
+        ctypes.byref(geom))) else 'f32'
+  elif name != 'f32':
+    name = 'bf16x3' if lib.vtc_conv_x3_supported(ctypes.byref(geom)) else (
+        'f32')
   for _ in range(num_iters):
     vtc_hip.check(lib.vtc_conv_dict_gradient(
         vtc_hip.ptr(images_padded), vtc_hip.ptr(dictionary),
         vtc_hip.ptr(codes), vtc_hip.ptr(grad_sum), ctypes.byref(geom),
-        vtc_hip.ptr(ws), ws.numel(), stream), 'vtc_conv_dict_gradient')
+        vtc_hip.PRECISIONS[name], vtc_hip.ptr(ws), ws.numel(), stream),
+        'vtc_conv_dict_gradient')
     parallel.all_reduce_sum_(grad_sum)
     vtc_hip.check(lib.vtc_conv_dict_apply(
         vtc_hip.ptr(dictionary), vtc_hip.ptr(grad_sum),

@@ -108,8 +108,8 @@ SIGNATURES = {
     'vtc_fc_dict_apply': (_i32, [_vp, _vp, _vp, _vp, _f32, _i64, _f32, _f32,
                                  _i32, _i64, _i64, _vp]),
     'vtc_conv_dict_gradient_workspace_bytes': (_sz, [_GEOM_P]),
-    'vtc_conv_dict_gradient': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _vp, _sz,
-                                      _vp]),
+    'vtc_conv_dict_gradient': (_i32, [_vp, _vp, _vp, _vp, _GEOM_P, _i32, _vp,
+                                      _sz, _vp]),
     'vtc_conv_dict_apply': (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _i64,
                                    _i64, _vp, _vp]),
     'vtc_code_energy_workspace_bytes': (_sz, [_i64, _i64, _i64]),
