@@ -20,14 +20,27 @@
 namespace vtc {
 
 // ---------------------------------------------------------------- slab sum
+// Fixed summation order: slab z goes to partial sum z mod 8, the eight partial
+// sums are combined pairwise.  (Eight independent chains keep eight loads in
+// flight per thread: with up to 1024 slabs of a small gradient a single chain
+// is latency bound -- 290 us for the convolutional gradient of configs[4],
+// more than the contraction that produced the slabs.)
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int slices,
                                    int64_t count, float* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += stride) {
-    float acc = slabs[i];
-    for (int z = 1; z < slices; ++z) acc += slabs[(int64_t)z * count + i];
-    out[i] = acc;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= slices; z += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        a[u] = add_rn(a[u], slabs[(int64_t)(z + u) * count + i]);
+    }
+    for (int u = 0; z < slices; ++z, ++u)
+      a[u] = add_rn(a[u], slabs[(int64_t)z * count + i]);
+    out[i] = add_rn(add_rn(add_rn(a[0], a[1]), add_rn(a[2], a[3])),
+                    add_rn(add_rn(a[4], a[5]), add_rn(a[6], a[7])));
   }
 }
 
