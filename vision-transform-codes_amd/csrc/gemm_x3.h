@@ -89,9 +89,29 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, half = lane >> 5;
+  // Block -> tile.  Workgroups are dealt round-robin to the 8 XCDs (one L2
+  // each).  With few column tiles the blocks of one row block -- which read
+  // the same rows of A -- are made to run on one XCD back to back: block L is
+  // on XCD L % 8, slots L / 8 walk the column tiles of row block
+  // (slot / tiles_n) * 8 + XCD.  (Residual product of configs[3], two column
+  // tiles: A was fetched twice, FETCH_SIZE 139 -> 82 MB per launch.)  With
+  // many column tiles the plain order already keeps a column tile (B operand)
+  // on one XCD, and the paired order costs more than it saves (measured on
+  // the gradient product, 32 column tiles: FETCH_SIZE 173 -> 219 MB).
   const int64_t tiles_n = (g.N + kX3BN - 1) / kX3BN;
-  const int64_t m0 = ((int64_t)blockIdx.x / tiles_n) * kX3BM;
-  const int64_t n0 = ((int64_t)blockIdx.x % tiles_n) * kX3BN;
+  const int64_t tiles_m = (g.M + kX3BM - 1) / kX3BM;
+  int64_t tile_m, tile_n;
+  if (tiles_n <= 8) {
+    const int64_t slot = (int64_t)blockIdx.x >> 3;
+    tile_m = (slot / tiles_n) * 8 + (blockIdx.x & 7);
+    tile_n = slot % tiles_n;
+  } else {
+    tile_m = (int64_t)blockIdx.x / tiles_n;
+    tile_n = (int64_t)blockIdx.x % tiles_n;
+  }
+  if (tile_m >= tiles_m) return;                   // whole block (grid padding)
+  const int64_t m0 = tile_m * kX3BM;
+  const int64_t n0 = tile_n * kX3BN;
   const int z = blockIdx.y;
   const int64_t k_begin = (int64_t)z * g.k_chunk;
   const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
@@ -223,7 +243,9 @@ static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
   int64_t chunk = ceil_div(ceil_div(K, k_slices), kX3BK) * kX3BK;
   if (chunk < kX3BK) chunk = kX3BK;
   GemmX3Args g{A, B, M, N, K, lda, ldb, chunk};
-  const int64_t tiles = ceil_div(M, kX3BM) * ceil_div(N, kX3BN);
+  // row blocks padded to a multiple of 8 (see the block -> tile map)
+  const int64_t tiles = ceil_div(ceil_div(M, kX3BM), 8) * 8 *
+                        ceil_div(N, kX3BN);
   if (tiles > 0x7fffffffLL) {
     set_error("gemm_x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
