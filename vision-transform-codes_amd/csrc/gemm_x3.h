@@ -227,6 +227,150 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   epi.block_end();
 }
 
+// Eight-wave variant for plain (per element) epilogues: same 128 x 128 x 32
+// block tile and LDS layout, waves 4 x 2 with 32 x 64 wave tiles.  Half the
+// accumulator and staging registers per wave let four waves share a SIMD (16
+// per CU instead of 8): the residual product of the subspace / tiled FC paths
+// runs latency bound on the operand loads with 8.
+template <class Epi>
+__global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
+  __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;          // 4 x 2
+  const int l31 = lane & 31, half = lane >> 5;
+  const int64_t tiles_n = (g.N + kX3BN - 1) / kX3BN;
+  const int64_t tiles_m = (g.M + kX3BM - 1) / kX3BM;
+  int64_t tile_m, tile_n;
+  if (tiles_n <= 8) {                               // see gemm_x3_kernel
+    const int64_t slot = (int64_t)blockIdx.x >> 3;
+    tile_m = (slot / tiles_n) * 8 + (blockIdx.x & 7);
+    tile_n = slot % tiles_n;
+  } else {
+    tile_m = (int64_t)blockIdx.x / tiles_n;
+    tile_n = (int64_t)blockIdx.x % tiles_n;
+  }
+  if (tile_m >= tiles_m) return;
+  const int64_t m0 = tile_m * kX3BM;
+  const int64_t n0 = tile_n * kX3BN;
+  const int z = blockIdx.y;
+  const int64_t k_begin = (int64_t)z * g.k_chunk;
+  const int64_t k_end = (k_begin + g.k_chunk < g.K) ? k_begin + g.k_chunk : g.K;
+  const int nk = (int)((k_end - k_begin + kX3BK - 1) / kX3BK);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // 128 rows x 32 k per operand = 1024 float4: 2 per thread
+  auto stage_load = [&](const float* P, int64_t ld, int64_t line0,
+                        int64_t lines, int64_t k0, float4 (&regs)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 512;
+      const int line = f >> 3, kq = f & 7;
+      const int64_t gl = line0 + line, gk = k0 + kq * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gl < lines && gk < k_end) {
+        const float* src = P + gl * ld + gk;
+        if (gk + 3 < k_end) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (gk + 1 < k_end) v.y = src[1];
+          if (gk + 2 < k_end) v.z = src[2];
+        }
+      }
+      regs[i] = v;
+    }
+  };
+  auto stage_store = [&](char* hi_base, char* lo_base,
+                         const float4 (&regs)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + i * 512;
+      const int line = f >> 3, kq = f & 7;
+      const float v[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+      x3_bf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (__bf16)v[k];
+        lo[k] = (__bf16)(v[k] - (float)hi[k]);
+      }
+      const int off = x3_lds_off(line, kq >> 1) + 8 * (kq & 1);
+      *reinterpret_cast<uint2*>(hi_base + off) = __builtin_bit_cast(uint2, hi);
+      *reinterpret_cast<uint2*>(lo_base + off) = __builtin_bit_cast(uint2, lo);
+    }
+  };
+
+  float4 ra[2], rb[2];
+  stage_load(g.A, g.lda, m0, g.M, k_begin, ra);
+  stage_load(g.B, g.ldb, n0, g.N, k_begin, rb);
+  stage_store(lds[0][0], lds[0][1], ra);
+  stage_store(lds[0][2], lds[0][3], rb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      const int64_t k0 = k_begin + (int64_t)(kt + 1) * kX3BK;
+      stage_load(g.A, g.lda, m0, g.M, k0, ra);
+      stage_load(g.B, g.ldb, n0, g.N, k0, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int chunk = 2 * kk + half;
+      const int arow = wm * 32 + l31;
+      const uint4 ah = *reinterpret_cast<const uint4*>(lds[cur][0] +
+                                                       x3_lds_off(arow, chunk));
+      const uint4 al = *reinterpret_cast<const uint4*>(lds[cur][1] +
+                                                       x3_lds_off(arow, chunk));
+      uint4 bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int brow = wn * 64 + t * 32 + l31;
+        bh[t] = *reinterpret_cast<const uint4*>(lds[cur][2] +
+                                                x3_lds_off(brow, chunk));
+        bl[t] = *reinterpret_cast<const uint4*>(lds[cur][3] +
+                                                x3_lds_off(brow, chunk));
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(x3_bf16x8, ah),
+            __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(x3_bf16x8, ah),
+            __builtin_bit_cast(x3_bf16x8, bl[ni]), acc[ni], 0, 0, 0);
+        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(x3_bf16x8, al),
+            __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[ni], 0, 0, 0);
+      }
+    }
+    if (more) {
+      stage_store(lds[cur ^ 1][0], lds[cur ^ 1][1], ra);
+      stage_store(lds[cur ^ 1][2], lds[cur ^ 1][3], rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int64_t col = n0 + wn * 64 + ni * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < g.M && col < g.N) epi(row, col, acc[ni][r], z);
+    }
+  }
+  epi.block_end();
+}
+
 // Usable when both operands allow aligned 16-byte loads along k.
 static inline bool gemm_x3_usable(const float* A, int64_t lda, const float* B,
                                   int64_t ldb) {
@@ -250,9 +394,15 @@ static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
     set_error("gemm_x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((gemm_x3_kernel<Epi>),
-                     dim3((unsigned)tiles, (unsigned)ceil_div(K, chunk)),
-                     dim3(256), 0, st, g, epi);
+  const dim3 grid((unsigned)tiles, (unsigned)ceil_div(K, chunk));
+  if constexpr (!epi_whole_tile<Epi>::value) {
+    // plain epilogues: the eight-wave kernel (same-box A/B: tiled FC path
+    // 6.02 -> 5.65 ms, configs[3] 41.5 -> 41.2 ms)
+    hipLaunchKernelGGL((gemm_x3_kernel8<Epi>), grid, dim3(512), 0, st, g, epi);
+    VTC_LAUNCH_CHECK();
+    return VTC_OK;
+  }
+  hipLaunchKernelGGL((gemm_x3_kernel<Epi>), grid, dim3(256), 0, st, g, epi);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
