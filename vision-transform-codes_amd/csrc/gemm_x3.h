@@ -265,35 +265,44 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // 128 rows x 32 k per operand = 1024 float4: 2 per thread
-  auto stage_load = [&](const float* P, int64_t ld, int64_t line0,
-                        int64_t lines, int64_t k0, float4 (&regs)[2]) {
+  // Operand tiles go global -> registers -> (split) -> LDS; 128 rows x 32 k
+  // per operand = 1024 float4, 2 per thread.  The loads are buffer loads:
+  // rows past the matrix are past the end of the resource and k past the
+  // slice gets an out-of-range offset, both read as zero -- no branches, so
+  // the compiler can count outstanding loads (s_waitcnt vmcnt(N)) and the
+  // loads of K step kt+2 really stay in flight while step kt computes (with
+  // guarded loads in their own basic blocks every wait was vmcnt(0) and each
+  // step paid a full memory round trip).
+  auto tile_rsrc = [&](const float* P, int64_t ld, int64_t line0,
+                       int64_t lines) {
+    const int64_t left = lines - line0 < 128 ? lines - line0 : 128;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(P + line0 * ld), 0,
+                                             (int)(left * ld * 4), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ars = tile_rsrc(g.A, g.lda, m0, g.M);
+  const __amdgpu_buffer_rsrc_t brs = tile_rsrc(g.B, g.ldb, n0, g.N);
+  auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rs, int64_t ld,
+                        int64_t k0, x3_u32x4 (&regs)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + i * 512;
       const int line = f >> 3, kq = f & 7;
-      const int64_t gl = line0 + line, gk = k0 + kq * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gl < lines && gk < k_end) {
-        const float* src = P + gl * ld + gk;
-        if (gk + 3 < k_end) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          v.x = src[0];
-          if (gk + 1 < k_end) v.y = src[1];
-          if (gk + 2 < k_end) v.z = src[2];
-        }
-      }
-      regs[i] = v;
+      const int64_t gk = k0 + kq * 4;
+      const unsigned vo = gk < k_end ? (unsigned)((line * ld + gk) * 4)
+                                     : 0x80000000u;
+      regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
     }
   };
   auto stage_store = [&](char* hi_base, char* lo_base,
-                         const float4 (&regs)[2]) {
+                         const x3_u32x4 (&regs)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + i * 512;
       const int line = f >> 3, kq = f & 7;
-      const float v[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+      const float v[4] = {__uint_as_float(regs[i][0]),
+                          __uint_as_float(regs[i][1]),
+                          __uint_as_float(regs[i][2]),
+                          __uint_as_float(regs[i][3])};
       x3_bf16x4 hi, lo;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -305,22 +314,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
       *reinterpret_cast<uint2*>(lo_base + off) = __builtin_bit_cast(uint2, lo);
     }
   };
-
-  float4 ra[2], rb[2];
-  stage_load(g.A, g.lda, m0, g.M, k_begin, ra);
-  stage_load(g.B, g.ldb, n0, g.N, k_begin, rb);
-  stage_store(lds[0][0], lds[0][1], ra);
-  stage_store(lds[0][2], lds[0][3], rb);
-  __syncthreads();
-
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      const int64_t k0 = k_begin + (int64_t)(kt + 1) * kX3BK;
-      stage_load(g.A, g.lda, m0, g.M, k0, ra);
-      stage_load(g.B, g.ldb, n0, g.N, k0, rb);
-    }
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int chunk = 2 * kk + half;
@@ -351,12 +345,35 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
             __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[ni], 0, 0, 0);
       }
     }
-    if (more) {
-      stage_store(lds[cur ^ 1][0], lds[cur ^ 1][1], ra);
-      stage_store(lds[cur ^ 1][2], lds[cur ^ 1][3], rb);
+  };
+  auto k_of = [&](int kt) { return k_begin + (int64_t)kt * kX3BK; };
+
+  // two register stages: loads of step kt+2 are issued during step kt
+  x3_u32x4 a0[2], b0[2], a1[2], b1[2];
+  stage_load(ars, g.lda, k_of(0), a0);
+  stage_load(brs, g.ldb, k_of(0), b0);
+  stage_store(lds[0][0], lds[0][1], a0);
+  stage_store(lds[0][2], lds[0][3], b0);
+  __syncthreads();
+  if (nk > 1) { stage_load(ars, g.lda, k_of(1), a0); stage_load(brs, g.ldb, k_of(1), b0); }
+  if (nk > 2) { stage_load(ars, g.lda, k_of(2), a1); stage_load(brs, g.ldb, k_of(2), b1); }
+  for (int kt = 0; kt < nk; kt += 2) {
+    compute(0);                                          // step kt
+    if (kt + 1 < nk) {
+      stage_store(lds[1][0], lds[1][1], a0);             // operands of kt+1
+      stage_store(lds[1][2], lds[1][3], b0);
     }
     __syncthreads();
-    cur ^= 1;
+    if (kt + 3 < nk) { stage_load(ars, g.lda, k_of(kt + 3), a0); stage_load(brs, g.ldb, k_of(kt + 3), b0); }
+    if (kt + 1 < nk) {
+      compute(1);                                        // step kt+1
+      if (kt + 2 < nk) {
+        stage_store(lds[0][0], lds[0][1], a1);           // operands of kt+2
+        stage_store(lds[0][2], lds[0][3], b1);
+      }
+      __syncthreads();
+      if (kt + 4 < nk) { stage_load(ars, g.lda, k_of(kt + 4), a1); stage_load(brs, g.ldb, k_of(kt + 4), b1); }
+    }
   }
 
 #pragma unroll
