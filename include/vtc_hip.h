@@ -17,7 +17,13 @@
  *     sc_cheap_quadratic_descent.py:14-79                             -> vtc_conv_dict_gradient, vtc_conv_dict_apply
  *   training/sparse_coding.py:154,160-161 (Hessian-diagonal EMA)      -> vtc_code_energy, vtc_hessian_ema
  *   the `torch.mm(dictionary.t(), dictionary)` of the Lipschitz step
- *     (ista_fista.py:73-74)                                           -> vtc_gram
+ *     (ista_fista.py:73-74) and its `torch.symeig(...)[0][-1]`         -> vtc_gram, vtc_lambda_max
+ *   training/sparse_coding.py:177-229 (validation metrics)            -> vtc_fc_residual, vtc_conv_residual, vtc_row_stats,
+ *                                                                        vtc_group_norm_sum, vtc_window_minmax,
+ *                                                                        vtc_rows_mean_abs_diff
+ *   utils/image_processing.py:267-308, utils/dataset_generation.py
+ *     :184-222 (whitening, patch extraction)                          -> vtc_whiten_center_surround, vtc_extract_patches
+ *   dict_update_rules/fully_connected/ica_natural_gradient.py:6-35    -> vtc_ica_moment, vtc_ica_apply
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous row-major float32 unless
