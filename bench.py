@@ -7,6 +7,10 @@ dictionary (BASELINE.json configs[1]; configs[2] when launched on N GPUs).
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
       --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+A plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts its
+N rank processes itself, before anything touches the GPU, and relays rank 0's
+JSON line.
+
 One process per GPU.  The patch batch shards by rows over the ranks (weak
 scaling: --batch patches per GPU); inference is rank-local; the un-normalised
 dictionary gradient is summed with one RCCL all-reduce per step.  Rank 0 prints
@@ -34,14 +38,18 @@ DICT_STEP = 0.1
 FLOP_PER_PATCH_ITER = 4 * N_ATOMS * N_PIX     # two contractions of 2*s*n
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense, no sparsity)
-PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f32': 157.3}
+PEAK_TFLOPS = {'bf16': 2500.0, 'bf16x3': 2500.0, 'f16x3': 2500.0,
+               'f32': 157.3}
 # a pure MFMA loop on the box (tools/peaks/peaks.hip, profiles/r01_peaks.txt)
-MEASURED_PEAK_TFLOPS = {'bf16': 2030.0, 'bf16x3': 2030.0, 'f32': 144.0}
+MEASURED_PEAK_TFLOPS = {'bf16': 2030.0, 'bf16x3': 2030.0, 'f16x3': 2030.0,
+                        'f32': 144.0}
 KERNEL_NAMES = {
     'bf16': 'vtc::fused_fista_kernel<8,1,SOFT> (one launch = all 200 '
             'iterations, state on chip)',
     'bf16x3': 'vtc::fused_fista_kernel<8,2,SOFT> (one launch = all 200 '
               'iterations, bf16 hi/lo split, 3 MFMA products)',
+    'f16x3': 'vtc::fused_fista_kernel<8,2,SOFT,F16> (one launch = all 200 '
+             'iterations, f16 hi/lo split in scaled units, 3 MFMA products)',
     'f32': 'vtc::gemm_f32_kernel pair x 200 (exact-f32 MFMA, general path)'}
 
 
@@ -53,7 +61,7 @@ def parse_args():
   ap.add_argument('--batch', type=int, default=0,
                   help='patches per GPU (0 = default for the precision)')
   ap.add_argument('--precision', default='auto',
-                  choices=['auto', 'f32', 'bf16x3', 'bf16'])
+                  choices=['auto', 'f32', 'f16x3', 'bf16x3', 'bf16'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-sample', type=int, default=4096,
                   help='patches in the CPU-baseline sample')
@@ -127,12 +135,39 @@ def cpu_baseline(sample):
                         sample, FISTA_ITERS, runs, cores)}
 
 
+def spawn_ranks(args):
+  """`python bench.py --gpus N` without a launcher: start N fresh child
+  processes (one per GPU, the torchrun environment contract) BEFORE this
+  process makes any GPU call, wait for them and exit with the worst code.
+  The children inherit stdout, so rank 0's JSON line is the output."""
+  import socket
+  import subprocess
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+  children = []
+  for rank in range(args.gpus):
+    env = dict(os.environ)
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank),
+                'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
+                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    children.append(subprocess.Popen([sys.executable] + sys.argv, env=env))
+  codes = [child.wait() for child in children]
+  return max(abs(c) for c in codes)
+
+
 def main():
   args = parse_args()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(spawn_ranks(args))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
-  assert world == args.gpus, 'launch one process per GPU (--gpus == WORLD_SIZE)'
+  if world != args.gpus:
+    raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one process '
+                     'per GPU, or drop the launcher and let bench.py spawn its '
+                     'ranks)' % (args.gpus, world))
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
 
@@ -151,7 +186,7 @@ def main():
 
   precision = args.precision
   if precision == 'auto':
-    precision = 'bf16x3' if ista_fista.fused_available() else 'f32'
+    precision = 'f16x3' if ista_fista.fused_available() else 'f32'
   batch = args.batch or (131072 if precision != 'f32' else 32768)
   X, D = synthetic_inputs(rank, batch, device)
 

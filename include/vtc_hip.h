@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define VTC_ABI_VERSION 2
+#define VTC_ABI_VERSION 3
 
 enum vtc_status {
   VTC_OK = 0,
@@ -74,7 +74,11 @@ enum vtc_threshold {
 enum vtc_precision {
   VTC_F32 = 0,    /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode    */
   VTC_BF16X3 = 1, /* bf16 hi/lo split, 3 MFMA products: ~f32 accuracy        */
-  VTC_BF16 = 2    /* single bf16 MFMA product, f32 accumulate: fast mode     */
+  VTC_BF16 = 2,   /* single bf16 MFMA product, f32 accumulate: fast mode     */
+  VTC_F16X3 = 3   /* f16 hi/lo split (11 + 11 bits) in power-of-two scaled
+                   * units, 3 MFMA products: ~2^-21 per product at the bf16x3
+                   * cost.  Fused fully-connected kernel only; elsewhere it
+                   * runs as VTC_BF16X3.                                      */
 };
 
 const char* vtc_version(void);
@@ -112,6 +116,18 @@ int vtc_fc_ista_fista(const float* images, const float* dictionary,
                       int threshold, float early_stopping_epsilon,
                       int precision, void* workspace, size_t workspace_bytes,
                       int* iters_run, void* stream);
+/* Same, with the step size read from DEVICE memory (e.g. out + 1 of
+ * vtc_lambda_max): the reference keeps `stepsize` as a 0-d device tensor and
+ * never brings it to the host (ista_fista.py:72-80), so a training step
+ * without early stopping needs no host synchronisation at all.  The threshold
+ * is float(sparsity_weight) * *stepsize_dev, formed on the device in f32. */
+int vtc_fc_ista_fista_dev(const float* images, const float* dictionary,
+                          const float* initial_codes, float* codes, int64_t b,
+                          int64_t n, int64_t s, const float* stepsize_dev,
+                          float sparsity_weight, int num_iters, int variant,
+                          int threshold, float early_stopping_epsilon,
+                          int precision, void* workspace,
+                          size_t workspace_bytes, int* iters_run, void* stream);
 
 /* ---- subspace inference (row a3) --------------------------------------- */
 /* index/valid describe the padded (G, m) layout: slot g*m+j holds dictionary

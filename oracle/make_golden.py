@@ -450,6 +450,58 @@ def make_trainer(ref):
   np.savez_compressed(GOLDEN / 'trainer.npz', **out)
 
 
+def trainer_c2_params():
+  """The parameter dictionary behind tests/golden/trainer_c2.npz (also used by
+  tests/test_pipeline_gpu.py)."""
+  return {
+      'mode': 'fully-connected', 'num_epochs': 1,
+      'code_inference_algorithm': 'fista',
+      'inference_param_schedule': {
+          0: {'sparsity_weight': 0.008, 'num_iters': 50}},
+      'dictionary_update_algorithm': 'sc_cheap_quadratic_descent',
+      'dict_update_param_schedule': {0: {'stepsize': 0.1, 'num_iters': 1}}}
+
+
+def make_trainer_c2(ref):
+  """Headline shape end to end: three steps of the reference's own
+  train_dictionary at n = 256, s = 1024 (b = 64, FISTA T = 50, cheap-quadratic
+  update).  Inputs are regenerated from their seeds by the test (patches seed
+  60, dictionary seed 61); stored: the dictionary after steps 1 and 3 (float32),
+  the step-2 dictionary as a checksum vector (row sums in float64), the
+  Hessian diagonal after step 3, the reference's stepsize eta at each step and
+  the codes of the first step."""
+  out = {}
+  X = gaussian_patches(60, 192, 256)
+  D0 = unit_rows(61, 1024, 256)
+  params = trainer_c2_params()
+  dicts = []
+  for steps in (1, 2, 3):
+    Dref = T(D0.copy())
+    sub = torch.utils.data.DataLoader(_ListDataset(T(X[:64 * steps])),
+                                      batch_size=64, shuffle=False)
+    ref.trainer.train_dictionary(sub, sub, Dref, dict(params))
+    dicts.append(Dref.numpy().copy())
+  out['dict_after_step1'] = dicts[0]
+  out['dict_after_step3'] = dicts[2]
+  out['dict_after_step2_rowsum'] = dicts[1].astype(np.float64).sum(axis=1)
+  out['dict_after_step2_colsum'] = dicts[1].astype(np.float64).sum(axis=0)
+  # eta the reference's inference used at each step (D0, D1, D2)
+  out['eta'] = np.array([ref_eta_fc(T(D0)), ref_eta_fc(T(dicts[0])),
+                         ref_eta_fc(T(dicts[1]))], np.float32)
+  out['codes_step1'] = ref.fc_inf.run(T(X[:64]), T(D0), 0.008, 50,
+                                      variant='fista').numpy()
+  Dm = T(D0.copy())
+  hist = sc_oracle.train_steps([T(X[64 * i: 64 * i + 64]) for i in range(3)],
+                               Dm, params)
+  for i in range(3):
+    report('trainer_c2 step %d' % (i + 1), hist[i]['dictionary'],
+           T(dicts[i]))
+  report('trainer_c2 codes step 1', hist[0]['codes'], T(out['codes_step1']))
+  out['hessian_after_step3'] = hist[2]['hessian'].numpy()
+  out['patch_seed'], out['dict_seed'] = np.int64(60), np.int64(61)
+  np.savez_compressed(GOLDEN / 'trainer_c2.npz', **out)
+
+
 def make_ica(ref):
   """F8: the ICA natural-gradient update rule (f4 sibling of the dictionary
   update plugins) on sparse codes, one and three iterations, square and
@@ -621,7 +673,8 @@ def make_whitened(ref):
 
 MAKERS = {'fc_c1': make_fc_c1, 'fc_c2_mini': make_fc_c2_mini,
           'subspace': make_subspace, 'conv': make_conv,
-          'trainer': make_trainer, 'whitened': make_whitened,
+          'trainer': make_trainer, 'trainer_c2': make_trainer_c2,
+          'whitened': make_whitened,
           'metrics': make_metrics, 'ica': make_ica}
 
 

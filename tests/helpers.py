@@ -7,11 +7,12 @@ import torch
 GOLDEN = pathlib.Path(__file__).resolve().parent / 'golden'
 
 # Tolerances.  north_star asks for codes within 1e-5 relative error of the
-# reference; SURVEY.md section 7 measured that the reference's own float32
-# result sits 1.2e-5..1.6e-5 away from a float64 run of the same algorithm
-# after 200 FISTA iterations, i.e. 1e-5 is the noise floor of the reference
-# itself.  The gates below are therefore:
-REL_TOL_F32 = 3e-5      # exact-f32 MFMA path and bf16x3 path, 200 iterations
+# reference with an identical support.  Measured on MI355X against the
+# reference's own codes after 200 FISTA iterations
+# (profiles/r02_precision_fc.txt): exact-f32 path 2.5e-6, f16x3 (the default
+# of the fused kernel) 2.5e-6, both with 0 support flips; bf16x3 1.75e-5.
+REL_TOL_F32 = 1e-5      # exact-f32 MFMA path and f16x3, 200 iterations
+REL_TOL_BF16X3 = 3e-5   # bf16 hi/lo split (2^-17 per product), 200 iterations
 REL_TOL_SHORT = 5e-6    # <= 50 iterations
 REL_TOL_DICT = 2e-6     # one dictionary update
 NEAR_THRESHOLD = 2e-6   # support flips are only tolerated this close to it

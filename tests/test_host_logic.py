@@ -125,7 +125,25 @@ def _dp_worker(rank, world, port, out_dir):
   # local un-normalised partials, exactly what the HIP gradient entry returns
   grad_sum = torch.mm(Cs.t(), torch.mm(Cs, D) - Xs)
   energy = (Cs * Cs).sum(0)
-  parallel.all_reduce_sum_(grad_sum, energy)      # packed: one collective
+  # the trainer's protocol: the code energy is deferred, rides on the
+  # gradient's all-reduce, and its callback (the Hessian EMA) runs after the
+  # sum and before the caller applies the gradient
+  order = []
+  seen_in_callback = {}
+
+  def ema_stand_in():
+    order.append('ema')
+    seen_in_callback['energy'] = energy.clone()
+  before = parallel.collectives_issued
+  parallel.defer(energy, ema_stand_in)
+  assert order == []                              # not yet: waits for the reduce
+  parallel.all_reduce_sum_(grad_sum)              # packed: ONE collective
+  order.append('apply')
+  assert order == ['ema', 'apply']
+  assert parallel.collectives_issued - before == 1
+  assert torch.equal(seen_in_callback['energy'], energy)
+  parallel.flush_deferred()                       # nothing left: no collective
+  assert parallel.collectives_issued - before == 1
   total = parallel.global_batch(Xs.shape[0], X.device)
   assert total == 64
   parallel.enable(equal_shards=False)
@@ -137,6 +155,53 @@ def _dp_worker(rank, world, port, out_dir):
              os.path.join(out_dir, 'rank%d.pt' % rank))
   dist.barrier()
   dist.destroy_process_group()
+
+
+def test_deferred_reduce_without_a_process_group_runs_at_once():
+  from vtc_hip import parallel
+  parallel.disable()
+  ran = []
+  parallel.defer(torch.ones(3), lambda: ran.append(1))
+  assert ran == [1]
+  parallel.flush_deferred()
+
+
+def test_bench_refuses_a_mismatched_launcher_and_spawns_without_one():
+  """bench.py --gpus N: under a launcher WORLD_SIZE must equal N; without one
+  it starts its own N rank processes before any GPU call (checked here only
+  up to the environment each child would get)."""
+  import importlib.util
+  import subprocess
+  import sys
+  repo = os.path.join(os.path.dirname(__file__), '..')
+  env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+  proc = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'),
+                         '--gpus', '4'], env=env, capture_output=True,
+                        text=True)
+  assert proc.returncode != 0 and 'WORLD_SIZE=2' in proc.stderr
+  spec = importlib.util.spec_from_file_location(
+      'bench_module', os.path.join(repo, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  launched = []
+
+  class FakeChild(object):
+    def __init__(self, argv, env):
+      launched.append(env)
+
+    def wait(self):
+      return 0
+  real = subprocess.Popen
+  subprocess.Popen = FakeChild
+  try:
+    args = type('A', (), {'gpus': 4})()
+    assert bench.spawn_ranks(args) == 0
+  finally:
+    subprocess.Popen = real
+  assert [e['RANK'] for e in launched] == ['0', '1', '2', '3']
+  assert all(e['WORLD_SIZE'] == '4' and e['MASTER_ADDR'] == '127.0.0.1'
+             for e in launched)
+  assert len(set(e['MASTER_PORT'] for e in launched)) == 1
 
 
 def test_data_parallel_update_matches_single_process(tmp_path):

@@ -36,15 +36,17 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
       after every iteration but the first; costs a host sync per iteration).
   nonnegative_only, hard_threshold : bool, choose among the four thresholding
       functions of the reference (ista_fista.py:107-120)
-  precision : None | 'auto' | 'f32' | 'bf16x3' | 'bf16' -- extension, see
-      vtc_hip.set_default_precision.  None uses the process-wide default.
-      'bf16x3' runs the fused persistent kernel when the shape allows
-      (n == 256, s a multiple of 128, no early stopping) and a tiled
-      bf16 hi/lo split contraction otherwise; 'bf16' exists only fused.
-      'auto' = 'bf16x3' for the fused kernel's shapes and for large problems
-      (b*s >= 2^22, n and s multiples of 4), 'f32' otherwise.
+  precision : None | 'auto' | 'f32' | 'f16x3' | 'bf16x3' | 'bf16' -- extension,
+      see vtc_hip.set_default_precision.  None uses the process-wide default.
+      'f16x3' / 'bf16x3' run the fused persistent kernel when the shape allows
+      (n == 256, s in {256, 512, 1024}, no early stopping) and a tiled bf16
+      hi/lo split contraction otherwise; 'bf16' exists only fused.
+      'auto' = 'f16x3' for the fused kernel's shapes, 'bf16x3' for other large
+      problems (b*s >= 2^22, n and s multiples of 4), 'f32' otherwise.
   stepsize : float, optional -- extension: skip the Lipschitz eigen-solve and
       use this eta (tests inject the eta of a golden vector this way).
+      Without it (and without early stopping) eta stays on the device, as the
+      reference's 0-d `stepsize` tensor does: the call only enqueues.
 
   Returns
   -------
@@ -67,29 +69,41 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
     raise UnboundLocalError(
         "local variable 'codes' referenced before assignment")
 
-  if stepsize is None:
-    # largest eigenvalue of D^T D (n x n), as ista_fista.py:72-80
-    stepsize = vtc_hip.stepsize_from_gram(
-        vtc_hip.gram(dictionary, transpose_a=True), dictionary)
-  eta = float(stepsize)
-  lam = float(sparsity_weight)
-
   mode = vtc_hip.threshold_mode(nonnegative_only, hard_threshold)
   prec = _resolve_precision(precision, b, n, s, early_stopping_epsilon)
+  lam = float(sparsity_weight)
+  eps = -1.0 if early_stopping_epsilon is None else float(
+      early_stopping_epsilon)
   ws_bytes = lib.vtc_fc_ista_fista_workspace_bytes(b, n, s, prec)
   ws = vtc_hip.workspace(ws_bytes, images.device)
   codes = torch.empty((b, s), dtype=torch.float32, device=images.device)
   iters_run = ctypes.c_int(0)
-  eps = -1.0 if early_stopping_epsilon is None else float(
-      early_stopping_epsilon)
-  with vtc_hip.timed_call(images.device):
-    status = lib.vtc_fc_ista_fista(
-        vtc_hip.ptr(images), vtc_hip.ptr(dictionary),
-        vtc_hip.ptr(initial_codes), vtc_hip.ptr(codes), b, n, s, eta, lam,
-        int(num_iters), vtc_hip.variant_code(variant), mode, eps, prec,
-        vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run),
-        vtc_hip.current_stream(images.device))
-  vtc_hip.check(status, 'vtc_fc_ista_fista')
+  common = (int(num_iters), vtc_hip.variant_code(variant), mode, eps, prec,
+            vtc_hip.ptr(ws), ws.numel(), ctypes.byref(iters_run),
+            vtc_hip.current_stream(images.device))
+  if (stepsize is None and early_stopping_epsilon is None and
+      vtc_hip.device_stepsize_available(n)):
+    # largest eigenvalue of D^T D (n x n), as ista_fista.py:72-80, kept on the
+    # device like the reference's 0-d `stepsize` tensor: nothing in this call
+    # waits for the GPU
+    eta_dev = vtc_hip.stepsize_on_device(
+        vtc_hip.gram(dictionary, transpose_a=True), dictionary)
+    with vtc_hip.timed_call(images.device):
+      status = lib.vtc_fc_ista_fista_dev(
+          vtc_hip.ptr(images), vtc_hip.ptr(dictionary),
+          vtc_hip.ptr(initial_codes), vtc_hip.ptr(codes), b, n, s,
+          vtc_hip.ptr(eta_dev), lam, *common)
+    vtc_hip.check(status, 'vtc_fc_ista_fista_dev')
+  else:
+    if stepsize is None:
+      stepsize = vtc_hip.stepsize_from_gram(
+          vtc_hip.gram(dictionary, transpose_a=True), dictionary)
+    with vtc_hip.timed_call(images.device):
+      status = lib.vtc_fc_ista_fista(
+          vtc_hip.ptr(images), vtc_hip.ptr(dictionary),
+          vtc_hip.ptr(initial_codes), vtc_hip.ptr(codes), b, n, s,
+          float(stepsize), lam, *common)
+    vtc_hip.check(status, 'vtc_fc_ista_fista')
   run.last_iters = iters_run.value
   return codes
 
@@ -103,10 +117,12 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
     # kernel's shapes, and large problems on the tiled contraction; the exact
     # f32 kernels for small or oddly sized ones
     fused_ok = (early_stopping_epsilon is None and n == 256 and
-                s % 128 == 0 and fused_available())
+                s in (256, 512, 1024) and fused_available())
     tiled_ok = (n % 4 == 0 and s % 4 == 0 and b * s >= (1 << 22) and
                 fused_available())
-    return vtc_hip.BF16X3 if (fused_ok or tiled_ok) else vtc_hip.F32
+    if fused_ok:
+      return vtc_hip.F16X3
+    return vtc_hip.BF16X3 if tiled_ok else vtc_hip.F32
   return vtc_hip.PRECISIONS[name]
 
 

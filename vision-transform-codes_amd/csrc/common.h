@@ -108,6 +108,16 @@ __device__ __forceinline__ float shrink(float c, float cutoff, int mode) {
   }
 }
 
+// Epilogue functors that can take their step size from device memory expose
+// resolve(); the contraction kernels call it once per thread before any use.
+template <class E>
+__device__ __forceinline__ auto resolve_epilogue(E& e, int)
+    -> decltype(e.resolve(), void()) {
+  e.resolve();
+}
+template <class E>
+__device__ __forceinline__ void resolve_epilogue(E&, long) {}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

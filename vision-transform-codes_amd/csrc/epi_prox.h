@@ -24,6 +24,16 @@ struct EpiGroupProx {
   double* delta_sum;
   double local;
   int mode;   // ELEMENTWISE: vtc_threshold of the fully-connected plugin
+  // sync-free callers: eta lives in device memory (vtc_lambda_max out[1]) and
+  // the threshold is lam * eta, one f32 multiply as on the host
+  const float* eta_dev = nullptr;
+  float lam = 0.f;
+  __device__ __forceinline__ void resolve() {
+    if (eta_dev) {
+      eta = *eta_dev;
+      cutoff = mul_rn(lam, eta);
+    }
+  }
   // rows of the block as buffer resources: a row past the batch is past the
   // end of the resource (reads give 0, writes are dropped)
   struct Ctx {

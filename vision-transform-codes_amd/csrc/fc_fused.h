@@ -8,11 +8,15 @@ namespace vtc {
 // Shapes the fused bf16 / bf16x3 kernel is built for.
 bool fused_shape_supported(int64_t b, int64_t n, int64_t s, int precision);
 size_t fused_workspace_bytes(int64_t b, int64_t n, int64_t s, int precision);
+// eta_dev != nullptr: the step size is read from device memory (eta ignored).
 int run_fused(const float* images, const float* dictionary,
               const float* initial_codes, float* codes, int64_t b, int64_t n,
-              int64_t s, float eta, float cutoff, int num_iters, int variant,
+              int64_t s, float eta, const float* eta_dev,
+              float sparsity_weight, int num_iters, int variant,
               int threshold, int precision, void* workspace,
               size_t workspace_bytes, int* iters_run, hipStream_t st);
+// iterations per call the fused kernel's momentum table covers
+int fused_max_iters();
 
 // host-side FISTA momentum schedule (fc_inference.hip)
 void fista_betas(int num_iters, std::vector<float>* out);

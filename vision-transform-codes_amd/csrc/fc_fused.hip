@@ -35,6 +35,18 @@
 // both operands, three products hi*hi + hi*lo + lo*hi accumulated in f32
 // (bf16x3, ~2^-16 relative per product: float32-level results on the bf16
 // matrix pipe).  State, epilogue and accumulation are f32 in both.
+//
+// F16 (with NP = 2): the same three products on an f16 hi/lo split -- 11 + 11
+// significand bits instead of 8 + 8, i.e. ~2^-21 per product at the same MFMA
+// rate and the same bytes.  f16 has 5 exponent bits, so the kernel works in
+// power-of-two scaled units: the dictionary is packed as sigma_D * D (one
+// global sigma_D, max |D| in [256, 512)), and each patch carries its own
+// sigma_Y = 2^(11 - e), e = exponent of max(||x||, ||y0||), so that the
+// residual and the codes sit around 2^11 whatever the data's magnitude; the
+// f32 state (Y, C, X) is kept in those units for the whole launch.  Scaling by
+// a power of two commutes with every IEEE operation of the epilogue (no
+// under/overflow at these magnitudes), so the iteration is the reference's
+// own, bit for bit, given the products; codes are scaled back on the way out.
 #include "fc_fused.h"
 
 #include <stdlib.h>
@@ -44,6 +56,8 @@ namespace vtc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 
 constexpr int kFP = 32;    // patches per workgroup
@@ -57,15 +71,58 @@ constexpr int kPhaseAtoms = 128;
 // atoms), lane l:
 //   D[128p + 16ks + 8(l>>5) + j][32nb + (l&31)]
 // LO = 0 stores bf16(x), LO = 1 stores bf16(x - float(bf16(x))).
-__device__ __forceinline__ __bf16 split_part(float x, int lo) {
+template <bool F16>
+__device__ __forceinline__ unsigned short split_part(float x, int lo) {
+  if (F16) {
+    const _Float16 hi = (_Float16)x;
+    const _Float16 r = lo ? (_Float16)(x - (float)hi) : hi;
+    return __builtin_bit_cast(unsigned short, r);
+  }
   const __bf16 hi = (__bf16)x;
-  if (!lo) return hi;
-  return (__bf16)(x - (float)hi);
+  const __bf16 r = lo ? (__bf16)(x - (float)hi) : hi;
+  return __builtin_bit_cast(unsigned short, r);
 }
 
+// F16: sigma_D = 2^(8 - floor(log2 max|D|)), so that max |sigma_D D| lies in
+// [256, 512): far from the f16 overflow (65504) and with the lo parts of all
+// but vanishing entries in the normal range.  One block; scale[0] = sigma_D,
+// scale[1] = 1 / sigma_D.
+__global__ __launch_bounds__(1024) void dictionary_scale_kernel(
+    const float* __restrict__ D, int64_t count, float* __restrict__ scale) {
+  __shared__ float part[16];
+  float m = 0.f;
+  // count = s * 256: 16-byte loads, four independent maxima in flight
+  const float4* D4 = reinterpret_cast<const float4*>(D);
+  float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  for (int64_t i = threadIdx.x; i < count / 4; i += 1024) {
+    const float4 v = D4[i];
+    m = fmaxf(m, fabsf(v.x));
+    m1 = fmaxf(m1, fabsf(v.y));
+    m2 = fmaxf(m2, fabsf(v.z));
+    m3 = fmaxf(m3, fabsf(v.w));
+  }
+  m = fmaxf(fmaxf(m, m1), fmaxf(m2, m3));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, part[k]);
+    int e = 0;
+    if (m > 0.f && m < __builtin_inff()) e = ilogbf(m);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    scale[0] = ldexpf(1.f, 8 - e);
+    scale[1] = ldexpf(1.f, e - 8);
+  }
+}
+
+template <bool F16>
 __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
-                                       __bf16* __restrict__ packA,
-                                       __bf16* __restrict__ packT, int lo) {
+                                       unsigned short* __restrict__ packA,
+                                       unsigned short* __restrict__ packT,
+                                       int lo,
+                                       const float* __restrict__ scale) {
+  const float sg = F16 ? scale[0] : 1.f;
   const int64_t frags = (int64_t)s * kFN / 8;  // 16-byte units per packing
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < frags;
        u += (int64_t)gridDim.x * blockDim.x) {
@@ -76,7 +133,8 @@ __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
       const int t = (int)(f >> 4), ks = (int)(f & 15);
       const float* src = D + (int64_t)(32 * t + r) * kFN + 16 * ks + 8 * h;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) packA[u * 8 + j] = split_part(src[j], lo);
+      for (int j = 0; j < 8; ++j)
+        packA[u * 8 + j] = split_part<F16>(src[j] * sg, lo);
     }
     {
       const int64_t f = u >> 6;  // = (p*8 + nb)*8 + ks
@@ -85,7 +143,7 @@ __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
           D + (int64_t)(128 * p + 16 * ks + 8 * h) * kFN + 32 * nb + r;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        packT[u * 8 + j] = split_part(src[(int64_t)j * kFN], lo);
+        packT[u * 8 + j] = split_part<F16>(src[(int64_t)j * kFN] * sg, lo);
     }
   }
 }
@@ -100,7 +158,11 @@ struct FusedParams {
   int64_t b;
   int s;
   int num_iters;
-  float eta, cutoff;
+  int fista;              // 0: ISTA, the gradient is evaluated at the codes
+  float eta, cutoff;      // used when eta_dev is null
+  const float* eta_dev;   // device scalar 1/L (vtc_lambda_max out[1]) or null
+  float lam;              // sparsity weight, cutoff = lam * *eta_dev
+  const float* dscale;    // F16: {sigma_D, 1 / sigma_D} (dictionary_scale_kernel)
   unsigned long long* stamps;  // diagnostic build only: 8 cycle sums
 };
 
@@ -118,8 +180,44 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4& u) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-#define VTC_MFMA(a, b, c) \
-  __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(b), c, 0, 0, 0)
+__device__ __forceinline__ f16x8 as_frag16(const uint4& u) {
+  return __builtin_bit_cast(f16x8, u);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16v mfma_frag(const uint4& a, const uint4& b,
+                                             const f32x16v& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_frag16(a), as_frag16(b),
+                                                  c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(a), as_frag(b), c, 0,
+                                                 0, 0);
+}
+#define VTC_MFMA(a, b, c) mfma_frag<F16>(a, b, c)
+
+// four f32 values -> their 16-bit hi parts and (NP == 2) lo parts, packed
+template <bool F16, int NP>
+__device__ __forceinline__ void split4(const float (&v)[4], uint2* hi_out,
+                                       uint2* lo_out) {
+  if (F16) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (_Float16)v[k];
+      if (NP == 2) lo[k] = (_Float16)(v[k] - (float)hi[k]);
+    }
+    *hi_out = __builtin_bit_cast(uint2, hi);
+    if (NP == 2) *lo_out = __builtin_bit_cast(uint2, lo);
+  } else {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      if (NP == 2) lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *hi_out = __builtin_bit_cast(uint2, hi);
+    if (NP == 2) *lo_out = __builtin_bit_cast(uint2, lo);
+  }
+}
 
 // LDS plan (bytes), NPH phases, NP precision parts, CREG phases of C in VGPRs:
 //   Cst : (NPH-CREG) x 16 KiB   previous codes, [phase][wave][group][lane] f32x4
@@ -142,7 +240,8 @@ struct FusedLds {
   static constexpr int cst_bytes = CL * 16384;
   static constexpr int yx_bytes = 2 * NP * kYxPart;
   static constexpr int rx_bytes = NP * kRxPart;
-  static constexpr int total = cst_bytes + yx_bytes + rx_bytes;
+  static constexpr int stat_bytes = 4 * 32 * 4;   // F16: per-wave residual maxima
+  static constexpr int total = cst_bytes + yx_bytes + rx_bytes + stat_bytes;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -163,8 +262,9 @@ __device__ __forceinline__ unsigned long long stamp_now() {
   return t;
 }
 
-template <int NPH, int NP, int MODE, bool STAMP = false>
+template <int NPH, int NP, int MODE, bool F16 = false, bool STAMP = false>
 __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
+  static_assert(!F16 || NP == 2, "the f16 split exists as three products only");
   using L = FusedLds<NPH, NP>;
   constexpr int CREG = L::CREG;
   constexpr int CR = CREG > 0 ? CREG : 1;
@@ -176,6 +276,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   char* Cst = smem;
   char* Yx = smem + L::cst_bytes;
   char* Rx = Yx + L::yx_bytes;
+  float* Stat = reinterpret_cast<float*>(Rx + L::rx_bytes);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -252,14 +353,89 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
       Y[p][4 * g + 1] = v.y;
       Y[p][4 * g + 2] = v.z;
       Y[p][4 * g + 3] = v.w;
+    }
+  }
+  // F16: the patch's power-of-two scale (header comment).  e = exponent of
+  // max(||x||, ||y0||) over the whole patch: partial sums of squares per lane,
+  // the two lane halves by a lane exchange, the four waves through LDS (the R
+  // exchange area is not in use yet).
+  float sigma_y = 1.f, inv_sigma_y = 1.f;   // per lane (= per patch)
+  float sigma_d = 1.f, inv_sigma_d = 1.f;
+  if (F16) {
+    float sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sx += Xr[nb][e] * Xr[nb][e];
+    if (warm) {
+#pragma unroll
+      for (int p = 0; p < NPH; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sy += Y[p][e] * Y[p][e];
+    }
+    sx += __shfl_xor(sx, 32, 64);
+    sy += __shfl_xor(sy, 32, 64);
+    float* red = reinterpret_cast<float*>(Rx);
+    if (h == 0) {
+      red[w * 64 + r] = sx;
+      red[w * 64 + 32 + r] = sy;
+    }
+    __syncthreads();
+    float tx = 0.f, ty = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      tx += red[v * 64 + r];
+      ty += red[v * 64 + 32 + r];
+    }
+    __syncthreads();
+    const float m2 = fmaxf(tx, ty);
+    int e2 = 0;
+    if (m2 > 0.f && m2 < __builtin_inff()) e2 = ilogbf(m2) >> 1;
+    e2 = e2 < -60 ? -60 : (e2 > 60 ? 60 : e2);
+    sigma_y = ldexpf(1.f, 11 - e2);
+    inv_sigma_y = ldexpf(1.f, e2 - 11);
+    sigma_d = P.dscale[0];
+    inv_sigma_d = P.dscale[1];
+    const float sx_scale = sigma_d * sigma_y;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Xr[nb][e] *= sx_scale;
+#pragma unroll
+    for (int p = 0; p < NPH; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Y[p][e] *= sigma_y;
+  }
+  // eta either came by value or sits in device memory (sync-free callers);
+  // lambda * eta is then the same single f32 multiply the host would do
+  float eta = P.eta, cutoff_l = P.cutoff;
+  if (P.eta_dev) {
+    eta = *P.eta_dev;
+    cutoff_l = mul_rn(P.lam, eta);
+  }
+  if (F16) {
+    // scaled units: eta_s * Gacc = sigma_Y * (eta * G) with Gacc = sigma_D
+    // sigma_R G, sigma_R = 2 sigma_Y; the threshold scales with the codes
+    // (per lane, i.e. per patch)
+    eta = eta * (0.5f * inv_sigma_d);
+    cutoff_l = cutoff_l * sigma_y;
+  }
+  // residual operand: Rs = (Racc - Xs) * r_scale = sigma_R * R with
+  // sigma_R = 2 sigma_Y (||Rs|| starts in [2^12, 2^13))
+  const float r_scale = F16 ? 2.f * inv_sigma_d : 1.f;
+#pragma unroll
+  for (int p = 0; p < NPH; ++p) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
       if (p < CREG) {
-        Cr[p < CREG ? p : 0][4 * g + 0] = v.x;
-        Cr[p < CREG ? p : 0][4 * g + 1] = v.y;
-        Cr[p < CREG ? p : 0][4 * g + 2] = v.z;
-        Cr[p < CREG ? p : 0][4 * g + 3] = v.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          Cr[p < CREG ? p : 0][4 * g + q] = Y[p][4 * g + q];
       } else {
         *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
-                                   g * 1024) = v;
+                                   g * 1024) =
+            make_float4(Y[p][4 * g + 0], Y[p][4 * g + 1], Y[p][4 * g + 2],
+                        Y[p][4 * g + 3]);
       }
     }
   }
@@ -272,18 +448,12 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   auto publish_y = [&](const f32x16v& y, int buf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      bf16x4 hi, lo;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float v = y[4 * g + k];
-        hi[k] = (__bf16)v;
-        if (NP == 2) lo[k] = (__bf16)(v - (float)hi[k]);
-      }
+      const float v4[4] = {y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]};
+      uint2 hi, lo;
+      split4<F16, NP>(v4, &hi, &lo);
       char* dst = Yx + buf * NP * kYxPart + yx_wr + 16 * g;
-      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
-      if (NP == 2)
-        *reinterpret_cast<uint2*>(dst + kYxPart) =
-            __builtin_bit_cast(uint2, lo);
+      *reinterpret_cast<uint2*>(dst) = hi;
+      if (NP == 2) *reinterpret_cast<uint2*>(dst + kYxPart) = lo;
     }
   };
 
@@ -356,22 +526,75 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   // R_{k+1} = Racc - X  ->  bf16 parts -> LDS (read back as B fragments by
   // every wave during step 1 of the next iteration)
   auto exchange_r = [&]() {
+    float v[2][16];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[nb][e] = sub_rn(Racc[nb][e], Xr[nb][e]);
+        if (F16) v[nb][e] *= r_scale;
+      }
+    if (F16) {
+      // f16 range guard.  With eta = 1/L the residual never grows past a small
+      // multiple of ||x|| (2^12 in these units), but a caller's own stepsize
+      // may make the iteration diverge -- as it does in f32 in the reference.
+      // When a patch's residual passes 2^13 all of its state drops by a power
+      // of two (exact, so the iteration goes on bit for bit as before, in
+      // smaller units): max over the patch through LDS, then a wave-uniform
+      // branch that is not taken in a convergent run.
+      float m = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[nb][e]));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      if (h == 0) Stat[w * 32 + r] = m;
+      __syncthreads();
+      const float M = fmaxf(fmaxf(Stat[r], Stat[32 + r]),
+                            fmaxf(Stat[64 + r], Stat[96 + r]));
+      float f = 1.f;
+      if (M > 8192.f && M < __builtin_inff()) f = ldexpf(1.f, 12 - ilogbf(M));
+      if (__any(f != 1.f)) {
+#pragma unroll
+        for (int p = 0; p < NPH; ++p)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Y[p][e] *= f;
+#pragma unroll
+        for (int p = 0; p < CR; ++p)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) Cr[p][e] *= f;
+#pragma unroll
+        for (int pl = 0; pl < L::CL; ++pl)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4* c4 = reinterpret_cast<float4*>(Cst + cst_ln + pl * 16384 +
+                                                   g * 1024);
+            float4 c = *c4;
+            c.x *= f; c.y *= f; c.z *= f; c.w *= f;
+            *c4 = c;
+          }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            Xr[nb][e] *= f;
+            v[nb][e] *= f;
+          }
+        cutoff_l *= f;
+        inv_sigma_y *= 1.f / f;
+      }
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 hi, lo;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float v = sub_rn(Racc[nb][4 * g + k], Xr[nb][4 * g + k]);
-          hi[k] = (__bf16)v;
-          if (NP == 2) lo[k] = (__bf16)(v - (float)hi[k]);
-        }
+        const float v4[4] = {v[nb][4 * g], v[nb][4 * g + 1], v[nb][4 * g + 2],
+                             v[nb][4 * g + 3]};
+        uint2 hi, lo;
+        split4<F16, NP>(v4, &hi, &lo);
         char* dst = Rx + rx_wr + 64 * nb + 16 * g;
-        *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
-        if (NP == 2)
-          *reinterpret_cast<uint2*>(dst + kRxPart) =
-              __builtin_bit_cast(uint2, lo);
+        *reinterpret_cast<uint2*>(dst) = hi;
+        if (NP == 2) *reinterpret_cast<uint2*>(dst + kRxPart) = lo;
       }
     }
 #pragma unroll
@@ -399,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
     for (int part = 0; part < NP; ++part)
       ring[part][i] = VTC_LOAD_SEG(part, 0, i);
 
-  const float eta = P.eta, cutoff = P.cutoff;
+  const bool fista = P.fista != 0;   // ISTA: every beta is 0
   unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
   unsigned long long t0 = 0, t1 = 0;
 #define VTC_STAMP(slot)                    \
@@ -433,9 +656,12 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
     const float co = (k == 0) ? cold4.x : (k == 1) ? cold4.y
                    : (k == 2) ? cold4.z : cold4.w;
     const float c = sub_rn(Y[p][e], mul_rn(eta, Gp[e]));
-    const float cn = shrink_fast<MODE>(c, cutoff);
-    const float d = sub_rn(cn, co);
-    Y[p][e] = add_rn(cn, mul_rn(beta, d));
+    const float cn = shrink_fast<MODE>(c, cutoff_l);
+    // ISTA runs with beta = 0: y = c + 0 * (c - c_old) = c exactly for finite
+    // codes.  (A code that has already overflowed to inf gives NaN one
+    // iteration before the reference's `y = codes` would -- ista_fista.py:133
+    // -- whose next residual inf * D - X is NaN as well.)
+    Y[p][e] = add_rn(cn, mul_rn(beta, sub_rn(cn, co)));
     cn4[k] = cn;
     if (k == 3) {
       if (p < CREG) {
@@ -446,18 +672,13 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
                                    g * 1024) =
             make_float4(cn4[0], cn4[1], cn4[2], cn4[3]);
       }
-      bf16x4 hi, lo;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v = Y[p][4 * g + q];
-        hi[q] = (__bf16)v;
-        if (NP == 2) lo[q] = (__bf16)(v - (float)hi[q]);
-      }
+      const float v4[4] = {Y[p][4 * g], Y[p][4 * g + 1], Y[p][4 * g + 2],
+                           Y[p][4 * g + 3]};
+      uint2 hi, lo;
+      split4<F16, NP>(v4, &hi, &lo);
       char* dst = Yx + (p & 1) * NP * kYxPart + yx_wr + 16 * g;
-      *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, hi);
-      if (NP == 2)
-        *reinterpret_cast<uint2*>(dst + kYxPart) =
-            __builtin_bit_cast(uint2, lo);
+      *reinterpret_cast<uint2*>(dst) = hi;
+      if (NP == 2) *reinterpret_cast<uint2*>(dst + kYxPart) = lo;
     }
   };
 
@@ -500,7 +721,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   };
 
   for (int it = 0; it < P.num_iters; ++it) {
-    const float beta = P.betas[it];
+    const float beta = fista ? P.betas[it] : 0.f;
     step1(0, 0, false, beta);
     VTC_STAMP(0)
 #pragma unroll
@@ -544,6 +765,12 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
         v = *reinterpret_cast<const float4*>(Cst + cst_ln +
                                              (p - CREG) * 16384 + g * 1024);
       }
+      if (F16) {
+        v.x *= inv_sigma_y;
+        v.y *= inv_sigma_y;
+        v.z *= inv_sigma_y;
+        v.w *= inv_sigma_y;
+      }
       if (live)
         *reinterpret_cast<float4*>(P.codes + patch * s + kPhaseAtoms * p +
                                    32 * w + 8 * g + 4 * h) = v;
@@ -557,305 +784,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
 #undef VTC_SEG_PHASE
 }
 
-// ===========================================================================
-// Variant 2 (bf16): the dictionary goes through LDS once per iteration.
-//
-// In the kernel above every dictionary byte reaches the CU twice per
-// iteration (row-wise fragments for step 1, transposed fragments for step 3),
-// and both MFMA phases run at the per-CU vector-memory rate (64 B/clk) rather
-// than at the MFMA rate (in-kernel stamps, profiles/r01_fused_stamps.txt).
-// Here a phase's 128 x 256 bf16 block (64 KiB) is copied ONCE by LDS-DMA
-// (global_load_lds_dwordx4, no VGPRs) into one of two LDS buffers; step 1 reads
-// its A fragments from it by rows (ds_read_b128) and step 3 reads the SAME image
-// transposed (ds_read_b64_tr_b16).  The global copy is pre-packed as the exact
-// LDS image, XOR-swizzled so that both read patterns are bank-conflict free:
-//   element (atom row r of the phase, pixel x) -> byte
-//   r*512 + (((x>>3) ^ f(r)) << 4) + (x&7)*2,   f(r) = 4*(r&3) + ((r>>3)&3)
-// With the LDS holding 2 x 64 KiB of dictionary the previous codes C move from
-// LDS to VGPRs (Y and C: 256 VGPRs per lane); the register ring disappears.
-// Two barriers per phase: after the epilogue (Y' published) and after step 3
-// (buffer and exchange area free; the barrier also drains the DMA issued one
-// phase ahead).
-// ===========================================================================
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-
-__global__ void pack_lds_image_kernel(const float* __restrict__ D, int s,
-                                      __bf16* __restrict__ image) {
-  const int64_t chunks = (int64_t)s * kFN / 8;
-  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < chunks;
-       u += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(u & 31);          // 8-pixel chunk of the row
-    const int64_t atom = u >> 5;
-    const int rl = (int)(atom & 127);     // row inside the phase
-    const int f = 4 * (rl & 3) + ((rl >> 3) & 3);
-    const float* src = D + atom * kFN + 8 * c;
-    __bf16* dst = image + (atom >> 7) * 32768 + (int64_t)rl * 256 +
-                  ((c ^ f) << 3);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = (__bf16)src[j];
-  }
-}
-
-constexpr int kDbufBytes = 65536;
-constexpr int kLdsV2Total = 2 * kDbufBytes + kYxPart + kRxPart;  // 156672
-
-template <int NPH, int MODE, bool STAMP = false>
-__global__ __launch_bounds__(256, 1) void fused_fista_lds_kernel(
-    FusedParams P) {
-  static_assert(NPH % 2 == 0, "buffer parity must continue across iterations");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Dbuf = smem;
-  char* Yx = smem + 2 * kDbufBytes;
-  char* Rx = Yx + kYxPart;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t patch = (int64_t)blockIdx.x * kFP + r;
-  const bool live = patch < P.b;
-  const int s = P.s;
-
-  // LDS lane bases (exchange areas as in the kernel above)
-  const int yx_rd = r * kYxRow + 16 * h;
-  const int yx_wr = r * kYxRow + 64 * w + 8 * h;
-  const int rx_rd = r * kRxRow + 16 * h;
-  const int rx_wr = r * kRxRow + 128 * w + 8 * h;
-  // step-1 row reads: row 32w + r of the phase image, chunk (2ks + h) ^ fR
-  const int fR = 4 * (r & 3) + ((r >> 3) & 3);
-  const int a_row = (32 * w + r) * 512;
-  // step-3 transposed reads: lane (rho, pi) of 16-lane group g16
-  const int rho = (lane & 15) >> 2, pi = lane & 3, g16 = (lane >> 4) & 1;
-  const int t_lane_chunk = ((pi >> 1) ^ h) | (g16 << 1) | ((rho & 1) << 2) |
-                           (((w & 1) ^ (rho >> 1)) << 3) | ((w >> 1) << 4);
-  const int t_row = (8 * h + rho) * 512 + 8 * (pi & 1);
-
-  // LDS-DMA through a buffer descriptor: one VGPR (lane * 16) for every copy,
-  // the piece address as a scalar offset.  (With flat pointers hipcc
-  // pre-computes a 64-bit VGPR address per piece and keeps all 16 * NPH of
-  // them live across the iteration loop.)
-  const __amdgpu_buffer_rsrc_t image_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)P.packA[0], 0, (int)((unsigned)s * kFN * 2u), 0x00020000);
-  const int dma_voff = lane * 16;
-  const int dma_wave = w * 16384;
-  // one phase = 64 pieces of 1 KiB; wave w copies pieces 16w .. 16w+15
-  auto dma_piece = [&](int p, int buf, int i) {
-    char* dst = Dbuf + buf * kDbufBytes + dma_wave;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        image_rsrc, (lds_void*)(dst + i * 1024), 16, dma_voff,
-        p * kDbufBytes + dma_wave + i * 1024, 0, 0);
-  };
-  auto dma_phase = [&](int p, int buf) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dma_piece(p, buf, i);
-  };
-
-  f32x16v Y[NPH], C[NPH], Xr[2], Racc[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (live)
-        v = *reinterpret_cast<const float4*>(
-            P.images + patch * kFN + 64 * w + 32 * nb + 8 * g + 4 * h);
-      Xr[nb][4 * g + 0] = v.x;
-      Xr[nb][4 * g + 1] = v.y;
-      Xr[nb][4 * g + 2] = v.z;
-      Xr[nb][4 * g + 3] = v.w;
-    }
-  }
-  const bool warm = (P.init != nullptr);
-#pragma unroll
-  for (int p = 0; p < NPH; ++p) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (warm && live)
-        v = *reinterpret_cast<const float4*>(
-            P.init + patch * s + kPhaseAtoms * p + 32 * w + 8 * g + 4 * h);
-      Y[p][4 * g + 0] = C[p][4 * g + 0] = v.x;
-      Y[p][4 * g + 1] = C[p][4 * g + 1] = v.y;
-      Y[p][4 * g + 2] = C[p][4 * g + 2] = v.z;
-      Y[p][4 * g + 3] = C[p][4 * g + 3] = v.w;
-    }
-  }
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
-
-  auto publish_y = [&](const f32x16v& y) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf16x4 hi;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hi[k] = (__bf16)y[4 * g + k];
-      *reinterpret_cast<uint2*>(Yx + yx_wr + 16 * g) =
-          __builtin_bit_cast(uint2, hi);
-    }
-  };
-
-  // step 3 from LDS buffer `buf`: Racc[nb] += D^T (transposed reads) x Y'.
-  // Operands are read one MFMA ahead; the sched_barrier per MFMA keeps hipcc
-  // from hoisting all 48 LDS reads of the step to its top (register blow-up).
-  auto tr_frag = [&](const char* base, int ks, int nb) {
-    const int kconst = ((ks & 1) << 1) | (nb << 2);
-    const int off = ((t_lane_chunk ^ kconst) << 4);
-    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(base + off +
-                                                   (16 * ks + 0) * 512));
-    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(base + off +
-                                                   (16 * ks + 4) * 512));
-    const uint2 l2 = __builtin_bit_cast(uint2, lo4);
-    const uint2 h2 = __builtin_bit_cast(uint2, hi4);
-    return make_uint4(l2.x, l2.y, h2.x, h2.y);
-  };
-  auto step3 = [&](int buf, int next_p, bool prefetch) {
-    const char* base = Dbuf + buf * kDbufBytes + t_row;
-    uint4 a_next = tr_frag(base, 0, 0);
-    uint4 yb_next = *reinterpret_cast<const uint4*>(Yx + yx_rd);
-    uint4 yb = yb_next;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ks = i >> 1, nb = i & 1;
-      const uint4 a = a_next;
-      if (nb == 0) {
-        yb = yb_next;
-        if (ks + 1 < 8)
-          yb_next =
-              *reinterpret_cast<const uint4*>(Yx + yx_rd + 32 * (ks + 1));
-      }
-      if (i + 1 < 16) a_next = tr_frag(base, (i + 1) >> 1, (i + 1) & 1);
-      Racc[nb] = VTC_MFMA(a, yb, Racc[nb]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  auto exchange_r = [&]() {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 hi;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          hi[k] = (__bf16)sub_rn(Racc[nb][4 * g + k], Xr[nb][4 * g + k]);
-        *reinterpret_cast<uint2*>(Rx + rx_wr + 64 * nb + 16 * g) =
-            __builtin_bit_cast(uint2, hi);
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) Racc[nb][e] = 0.f;
-    __syncthreads();
-  };
-
-  // ---- R_0 = Y_0 D - X ---------------------------------------------------
-  if (warm) {
-#pragma unroll
-    for (int p = 0; p < NPH; ++p) {
-      dma_phase(p, p & 1);
-      publish_y(Y[p]);
-      __syncthreads();          // drains the DMA, publishes Y'
-      step3(p & 1, 0, false);
-      __syncthreads();
-    }
-  }
-  exchange_r();
-  dma_phase(0, 0);
-  __syncthreads();
-
-  const float eta = P.eta, cutoff = P.cutoff;
-  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
-  unsigned long long t0 = 0, t1 = 0;
-#define VTC_STAMP(slot)                    \
-  if (STAMP) {                             \
-    t1 = stamp_now();                      \
-    acc_t[slot] += t1 - t0;                \
-    t0 = t1;                               \
-  }
-  if (STAMP) t0 = stamp_now();
-  for (int it = 0; it < P.num_iters; ++it) {
-    const float beta = P.betas[it];
-#pragma unroll
-    for (int p = 0; p < NPH; ++p) {
-      // prefetch the next phase into the other buffer (free since the barrier
-      // that closed the previous phase).  Measured on MI355X: a 1 KiB LDS-DMA
-      // piece costs the issuing wave ~200 cycles wherever it is placed (as one
-      // burst here: step 1 = 2186 cycles; sprinkled between the MFMAs of
-      // step 1 / step 3: 2255 / 1481), i.e. the LDS-DMA path delivers less
-      // than the plain buffer loads of the register-ring variant, which is why
-      // this variant is not the default.
-      dma_phase((p + 1) % NPH, (p + 1) & 1);
-      // ---- step 1: G = D[tile] R_k, A fragments by rows from LDS
-      f32x16v G;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) G[e] = 0.f;
-      const char* abase = Dbuf + (p & 1) * kDbufBytes + a_row;
-      uint4 a_next =
-          *reinterpret_cast<const uint4*>(abase + (((0 + h) ^ fR) << 4));
-      uint4 rb_next = *reinterpret_cast<const uint4*>(Rx + rx_rd);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint4 a = a_next, rb = rb_next;
-        if (i + 1 < 16) {
-          a_next = *reinterpret_cast<const uint4*>(
-              abase + (((2 * (i + 1) + h) ^ fR) << 4));
-          rb_next =
-              *reinterpret_cast<const uint4*>(Rx + rx_rd + 32 * (i + 1));
-        }
-        G = VTC_MFMA(a, rb, G);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      VTC_STAMP(0)
-      // ---- proximal step + extrapolation (ista_fista.py:105-131)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float c = sub_rn(Y[p][e], mul_rn(eta, G[e]));
-        const float cn = shrink_fast<MODE>(c, cutoff);
-        const float d = sub_rn(cn, C[p][e]);
-        Y[p][e] = add_rn(cn, mul_rn(beta, d));
-        C[p][e] = cn;
-      }
-      publish_y(Y[p]);
-      VTC_STAMP(1)
-      // Y' visible to the other waves; LDS writes only, the DMA stays in flight
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      VTC_STAMP(2)
-      step3(p & 1, (p + 1) % NPH, true);
-      VTC_STAMP(3)
-      __syncthreads();   // buffer p&1 and Yx free; next phase's DMA landed
-      VTC_STAMP(2)
-    }
-    exchange_r();
-    VTC_STAMP(4)
-  }
-  if (STAMP && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) atomicAdd(P.stamps + k, acc_t[k]);
-    atomicAdd(P.stamps + 7, 1ull);
-  }
-#undef VTC_STAMP
-
-#pragma unroll
-  for (int p = 0; p < NPH; ++p) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (live)
-        *reinterpret_cast<float4*>(P.codes + patch * s + kPhaseAtoms * p +
-                                   32 * w + 8 * g + 4 * h) =
-            make_float4(C[p][4 * g + 0], C[p][4 * g + 1], C[p][4 * g + 2],
-                        C[p][4 * g + 3]);
-    }
-  }
-}
-
 }  // namespace vtc
-#include "fc_fused_priv.h"
 namespace vtc {
 
 // -------------------------------------------------------------------- host
@@ -866,21 +795,22 @@ bool fused_shape_supported(int64_t b, int64_t n, int64_t s, int precision) {
   if (s % kPhaseAtoms != 0) return false;
   const int nph = phases_for(s);
   if (!(nph == 2 || nph == 4 || nph == 8)) return false;
-  return precision == VTC_BF16 || precision == VTC_BF16X3;
+  return precision == VTC_BF16 || precision == VTC_BF16X3 ||
+         precision == VTC_F16X3;
 }
 
-static size_t pack_bytes(int64_t s) { return (size_t)s * kFN * sizeof(__bf16); }
+static size_t pack_bytes(int64_t s) { return (size_t)s * kFN * 2; }
 
 size_t fused_workspace_bytes(int64_t b, int64_t n, int64_t s, int precision) {
   if (!fused_shape_supported(b, n, s, precision)) return 256;
-  const int parts = (precision == VTC_BF16X3) ? 2 : 1;
-  return (size_t)parts * 2 * align_up(pack_bytes(s), 256) + 4096 * sizeof(float);
+  const int parts = (precision == VTC_BF16) ? 1 : 2;
+  return (size_t)parts * 2 * align_up(pack_bytes(s), 256) + 256;
 }
 
-template <int NPH, int NP, int MODE>
+template <int NPH, int NP, int MODE, bool F16>
 static int launch_fused(const FusedParams& P, hipStream_t st) {
   using L = FusedLds<NPH, NP>;
-  auto kernel = fused_fista_kernel<NPH, NP, MODE>;
+  auto kernel = fused_fista_kernel<NPH, NP, MODE, F16>;
   static unsigned long long configured = 0;
   if (first_use_on_this_device(&configured)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
@@ -896,10 +826,10 @@ static int launch_fused(const FusedParams& P, hipStream_t st) {
 // Diagnostic: VTC_FUSED_STAMPS=1 runs the stamped instantiation (soft
 // threshold only) and prints per-segment cycle shares.  Its run time is not
 // representative (the stamps fence the schedule); read the shares only.
-template <int NPH, int NP>
+template <int NPH, int NP, bool F16>
 static int launch_stamped(FusedParams P, hipStream_t st) {
   using L = FusedLds<NPH, NP>;
-  auto kernel = fused_fista_kernel<NPH, NP, VTC_SOFT, true>;
+  auto kernel = fused_fista_kernel<NPH, NP, VTC_SOFT, F16, true>;
   unsigned long long* dev = nullptr;
   VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
   VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
@@ -926,162 +856,70 @@ static int launch_stamped(FusedParams P, hipStream_t st) {
   return VTC_OK;
 }
 
-template <int NPH, int NP>
+template <int NPH, int NP, bool F16>
 static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
-  if (threshold == VTC_SOFT && NPH == 8 && getenv("VTC_FUSED_STAMPS"))
-    return launch_stamped<NPH, NP>(P, st);
+  static const bool stamps = getenv("VTC_FUSED_STAMPS") != nullptr;
+  if (stamps && threshold == VTC_SOFT && NPH == 8 && NP == 2)
+    return launch_stamped<NPH, NP, F16>(P, st);
   switch (threshold) {
-    case VTC_SOFT: return launch_fused<NPH, NP, VTC_SOFT>(P, st);
-    case VTC_SOFT_NONNEG: return launch_fused<NPH, NP, VTC_SOFT_NONNEG>(P, st);
-    case VTC_HARD: return launch_fused<NPH, NP, VTC_HARD>(P, st);
-    default: return launch_fused<NPH, NP, VTC_HARD_NONNEG>(P, st);
-  }
-}
-
-// ---- variant 2 (LDS-staged dictionary, bf16) ------------------------------
-static void print_stamps(const unsigned long long* host, int num_iters,
-                         int nph, const char* const* names) {
-  double total = 0;
-  for (int k = 0; k < 5; ++k) total += (double)host[k];
-  const double per = (double)host[7] * num_iters * nph;
-  for (int k = 0; k < 5; ++k)
-    fprintf(stderr, "[vtc stamps] %-9s %5.1f%%  %8.0f cycles/phase/wave\n",
-            names[k], 100.0 * host[k] / total, host[k] / per);
-}
-
-template <int NPH, int MODE, bool STAMP>
-static int launch_lds(FusedParams P, hipStream_t st) {
-  auto kernel = fused_fista_lds_kernel<NPH, MODE, STAMP>;
-  static unsigned long long configured = 0;
-  if (first_use_on_this_device(&configured)) {
-    VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsV2Total));
-  }
-  unsigned long long* dev = nullptr;
-  if (STAMP) {
-    VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
-    VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
-    P.stamps = dev;
-  }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
-                     kLdsV2Total, st, P);
-  VTC_LAUNCH_CHECK();
-  if (STAMP) {
-    unsigned long long host[8];
-    VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host),
-                                 hipMemcpyDeviceToHost, st));
-    VTC_HIP_CHECK(hipStreamSynchronize(st));
-    VTC_HIP_CHECK(hipFree(dev));
-    const char* names[5] = {"step1", "epilogue", "barriers", "step3",
-                            "exchange"};
-    print_stamps(host, P.num_iters, NPH, names);
-  }
-  return VTC_OK;
-}
-
-template <int NPH>
-static int dispatch_lds_mode(const FusedParams& P, int threshold,
-                             hipStream_t st) {
-  if (threshold == VTC_SOFT && getenv("VTC_FUSED_STAMPS"))
-    return launch_lds<NPH, VTC_SOFT, true>(P, st);
-  switch (threshold) {
-    case VTC_SOFT: return launch_lds<NPH, VTC_SOFT, false>(P, st);
+    case VTC_SOFT: return launch_fused<NPH, NP, VTC_SOFT, F16>(P, st);
     case VTC_SOFT_NONNEG:
-      return launch_lds<NPH, VTC_SOFT_NONNEG, false>(P, st);
-    case VTC_HARD: return launch_lds<NPH, VTC_HARD, false>(P, st);
-    default: return launch_lds<NPH, VTC_HARD_NONNEG, false>(P, st);
+      return launch_fused<NPH, NP, VTC_SOFT_NONNEG, F16>(P, st);
+    case VTC_HARD: return launch_fused<NPH, NP, VTC_HARD, F16>(P, st);
+    default: return launch_fused<NPH, NP, VTC_HARD_NONNEG, F16>(P, st);
   }
 }
 
-static int dispatch_lds(const FusedParams& P, int threshold, hipStream_t st) {
-  switch (phases_for(P.s)) {
-    case 2: return dispatch_lds_mode<2>(P, threshold, st);
-    case 4: return dispatch_lds_mode<4>(P, threshold, st);
-    case 8: return dispatch_lds_mode<8>(P, threshold, st);
-  }
-  set_error("fused FISTA: unsupported atom count %d", P.s);
-  return VTC_ERR_UNSUPPORTED;
-}
-
-// ---- variant 3 (private transposition, bf16) ------------------------------
-template <int NPH, int MODE, bool STAMP>
-static int launch_priv(FusedParams P, hipStream_t st) {
-  auto kernel = fused_fista_priv_kernel<NPH, MODE, STAMP>;
-  static unsigned long long configured = 0;
-  if (first_use_on_this_device(&configured)) {
-    VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, PrivLds<NPH>::total));
-  }
-  unsigned long long* dev = nullptr;
-  if (STAMP) {
-    VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
-    VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
-    P.stamps = dev;
-  }
-  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
-                     PrivLds<NPH>::total, st, P);
-  VTC_LAUNCH_CHECK();
-  if (STAMP) {
-    unsigned long long host[8];
-    VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host),
-                                 hipMemcpyDeviceToHost, st));
-    VTC_HIP_CHECK(hipStreamSynchronize(st));
-    VTC_HIP_CHECK(hipFree(dev));
-    const char* names[5] = {"step1", "epilogue", "-", "step3", "reduce-R"};
-    print_stamps(host, P.num_iters, NPH, names);
-  }
-  return VTC_OK;
-}
-
-template <int NPH>
-static int dispatch_priv_mode(const FusedParams& P, int threshold,
-                              hipStream_t st) {
-  if (threshold == VTC_SOFT && getenv("VTC_FUSED_STAMPS"))
-    return launch_priv<NPH, VTC_SOFT, true>(P, st);
-  switch (threshold) {
-    case VTC_SOFT: return launch_priv<NPH, VTC_SOFT, false>(P, st);
-    case VTC_SOFT_NONNEG:
-      return launch_priv<NPH, VTC_SOFT_NONNEG, false>(P, st);
-    case VTC_HARD: return launch_priv<NPH, VTC_HARD, false>(P, st);
-    default: return launch_priv<NPH, VTC_HARD_NONNEG, false>(P, st);
-  }
-}
-
-static int dispatch_priv(const FusedParams& P, int threshold, hipStream_t st) {
-  switch (phases_for(P.s)) {
-    case 2: return dispatch_priv_mode<2>(P, threshold, st);
-    case 4: return dispatch_priv_mode<4>(P, threshold, st);
-    case 8: return dispatch_priv_mode<8>(P, threshold, st);
-  }
-  set_error("fused FISTA: unsupported atom count %d", P.s);
-  return VTC_ERR_UNSUPPORTED;
-}
-
-template <int NP>
+template <int NP, bool F16>
 static int dispatch_phases(const FusedParams& P, int threshold,
                            hipStream_t st) {
   switch (phases_for(P.s)) {
-    case 2: return dispatch_mode<2, NP>(P, threshold, st);
-    case 4: return dispatch_mode<4, NP>(P, threshold, st);
-    case 8: return dispatch_mode<8, NP>(P, threshold, st);
+    case 2: return dispatch_mode<2, NP, F16>(P, threshold, st);
+    case 4: return dispatch_mode<4, NP, F16>(P, threshold, st);
+    case 8: return dispatch_mode<8, NP, F16>(P, threshold, st);
   }
   set_error("fused FISTA: unsupported atom count %d", P.s);
   return VTC_ERR_UNSUPPORTED;
 }
 
+// The FISTA momentum table beta_k = (t_k - 1) / t_{k+1} (ista_fista.py:123-127,
+// float64 recurrence rounded to f32) does not depend on the call: one copy per
+// device, filled from the host table on the first call there (a blocking
+// 64 KiB copy, once); afterwards a call only enqueues.
+constexpr int kBetaTable = 16384;
+static const float* beta_table_on_this_device() {
+  static float* tables[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
+  if (tables[dev]) return tables[dev];
+  std::vector<float> host;
+  fista_betas(kBetaTable, &host);
+  float* table = nullptr;
+  if (hipMalloc(&table, sizeof(float) * kBetaTable) != hipSuccess)
+    return nullptr;
+  if (hipMemcpy(table, host.data(), sizeof(float) * kBetaTable,
+                hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(table);
+    return nullptr;
+  }
+  tables[dev] = table;
+  return table;
+}
+
+int fused_max_iters() { return kBetaTable; }
+
 int run_fused(const float* images, const float* dictionary,
               const float* initial_codes, float* codes, int64_t b, int64_t n,
-              int64_t s, float eta, float cutoff, int num_iters, int variant,
+              int64_t s, float eta, const float* eta_dev,
+              float sparsity_weight, int num_iters, int variant,
               int threshold, int precision, void* workspace,
               size_t workspace_bytes, int* iters_run, hipStream_t st) {
   if (!fused_shape_supported(b, n, s, precision)) {
     set_error("fused FISTA: unsupported shape");
     return VTC_ERR_UNSUPPORTED;
   }
-  if (num_iters > 4096) {
-    set_error("fused FISTA: at most 4096 iterations per call");
+  if (num_iters > kBetaTable) {
+    set_error("fused FISTA: at most %d iterations per call", kBetaTable);
     return VTC_ERR_UNSUPPORTED;
   }
   if (!workspace ||
@@ -1089,44 +927,37 @@ int run_fused(const float* images, const float* dictionary,
     set_error("fused FISTA: workspace too small");
     return VTC_ERR_WORKSPACE;
   }
-  const int parts = (precision == VTC_BF16X3) ? 2 : 1;
+  const float* betas_dev = beta_table_on_this_device();
+  if (!betas_dev) {
+    set_error("fused FISTA: could not place the momentum table on the device");
+    return VTC_ERR_HIP;
+  }
+  const int parts = (precision == VTC_BF16) ? 1 : 2;
+  const bool f16 = (precision == VTC_F16X3);
   Carver ws(workspace);
   FusedParams P;
-  __bf16* packs[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned short* packs[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int part = 0; part < parts; ++part) {
-    packs[2 * part] = ws.take<__bf16>((size_t)s * kFN);
-    packs[2 * part + 1] = ws.take<__bf16>((size_t)s * kFN);
+    packs[2 * part] = ws.take<unsigned short>((size_t)s * kFN);
+    packs[2 * part + 1] = ws.take<unsigned short>((size_t)s * kFN);
   }
-  float* betas_dev = ws.take<float>(4096);
-  // bf16: VTC_FUSED_VARIANT=2 selects the experimental LDS-staged variant
-  // (same results bit for bit; slower on MI355X, see its header); the
-  // register-ring variant is the default and the only one for bf16x3
-  const char* variant_env = getenv("VTC_FUSED_VARIANT");
-  const bool use_lds_variant =
-      (parts == 1) && variant_env && variant_env[0] == '2';
-  if (use_lds_variant) {
-    hipLaunchKernelGGL(pack_lds_image_kernel, dim3(256), dim3(256), 0, st,
-                       dictionary, (int)s, packs[0]);
+  float* dscale = ws.take<float>(2);
+  if (f16) {
+    hipLaunchKernelGGL(dictionary_scale_kernel, dim3(1), dim3(1024), 0, st,
+                       dictionary, (int64_t)s * kFN, dscale);
     VTC_LAUNCH_CHECK();
-  } else {
-    for (int part = 0; part < parts; ++part) {
-      hipLaunchKernelGGL(pack_dictionary_kernel, dim3(256), dim3(256), 0, st,
-                         dictionary, (int)s, packs[2 * part],
-                         packs[2 * part + 1], part);
-      VTC_LAUNCH_CHECK();
-    }
   }
-  // ISTA is FISTA with beta = 0: y = c + 0 * (c - c_prev) = c exactly
-  std::vector<float> betas;
-  fista_betas(num_iters, &betas);
-  if (variant == VTC_ISTA)
-    for (auto& v : betas) v = 0.f;
-  // the staging buffer must outlive the async copy: keep it per thread
-  static thread_local std::vector<float> staged;
-  staged = betas;
-  VTC_HIP_CHECK(hipMemcpyAsync(betas_dev, staged.data(),
-                               sizeof(float) * num_iters,
-                               hipMemcpyHostToDevice, st));
+  for (int part = 0; part < parts; ++part) {
+    if (f16)
+      hipLaunchKernelGGL(pack_dictionary_kernel<true>, dim3(256), dim3(256), 0,
+                         st, dictionary, (int)s, packs[2 * part],
+                         packs[2 * part + 1], part, dscale);
+    else
+      hipLaunchKernelGGL(pack_dictionary_kernel<false>, dim3(256), dim3(256),
+                         0, st, dictionary, (int)s, packs[2 * part],
+                         packs[2 * part + 1], part, dscale);
+    VTC_LAUNCH_CHECK();
+  }
   P.images = images;
   P.init = initial_codes;
   P.codes = codes;
@@ -1139,15 +970,17 @@ int run_fused(const float* images, const float* dictionary,
   P.b = b;
   P.s = (int)s;
   P.num_iters = num_iters;
+  P.fista = (variant == VTC_FISTA) ? 1 : 0;
   P.eta = eta;
-  P.cutoff = cutoff;
+  P.eta_dev = eta_dev;
+  P.lam = sparsity_weight;
+  // lambda * eta: the Python float rounded to f32, then one f32 multiply
+  P.cutoff = sparsity_weight * eta;
+  P.dscale = dscale;
   P.stamps = nullptr;
-  const bool use_priv_variant =
-      (parts == 1) && variant_env && variant_env[0] == '3';
-  int rc = use_lds_variant    ? dispatch_lds(P, threshold, st)
-           : use_priv_variant ? dispatch_priv(P, threshold, st)
-           : (parts == 2)     ? dispatch_phases<2>(P, threshold, st)
-                              : dispatch_phases<1>(P, threshold, st);
+  int rc = f16          ? dispatch_phases<2, true>(P, threshold, st)
+           : parts == 2 ? dispatch_phases<2, false>(P, threshold, st)
+                        : dispatch_phases<1, false>(P, threshold, st);
   if (rc == VTC_OK && iters_run) *iters_run = num_iters;
   return rc;
 }

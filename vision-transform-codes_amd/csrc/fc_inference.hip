@@ -30,6 +30,14 @@ struct EpiProx {
   int fista;       // 0: Y and C are the same buffer
   double* delta_sum;  // sum |C - C_prev| / eta, or nullptr
   double local;
+  const float* eta_dev = nullptr;   // sync-free callers, see epi_prox.h
+  float lam = 0.f;
+  __device__ __forceinline__ void resolve() {
+    if (eta_dev) {
+      eta = *eta_dev;
+      cutoff = mul_rn(lam, eta);
+    }
+  }
 
   __device__ __forceinline__ void operator()(int64_t row, int64_t col, float g,
                                              int) {
@@ -82,10 +90,13 @@ static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
 // x3 = false: exact-f32 MFMA; x3 = true: bf16 hi/lo split tiles (gemm_x3.h)
 static int run_generic(const float* images, const float* dictionary,
                        const float* initial_codes, float* codes, int64_t b,
-                       int64_t n, int64_t s, float eta, float cutoff,
-                       int num_iters, int variant, int threshold, float eps,
-                       bool x3, void* workspace, size_t workspace_bytes,
-                       int* iters_run, hipStream_t st) {
+                       int64_t n, int64_t s, float eta, const float* eta_dev,
+                       float lam, int num_iters, int variant, int threshold,
+                       float eps, bool x3, void* workspace,
+                       size_t workspace_bytes, int* iters_run, hipStream_t st) {
+  // lambda * eta: the Python float rounded to f32, then one f32 multiply (the
+  // epilogues redo it on the device when eta lives there)
+  const float cutoff = lam * eta;
   if (workspace_bytes < generic_workspace_bytes(b, n, s) || !workspace) {
     set_error("vtc_fc_ista_fista: workspace too small (%zu < %zu)",
               workspace_bytes, generic_workspace_bytes(b, n, s));
@@ -153,13 +164,14 @@ static int run_generic(const float* images, const float* dictionary,
       EpiGroupProx<1, true> e2{Y, codes, s, eta, cutoff,
                                fista ? betas[k] : 0.f, fista ? 1 : 0,
                                eps >= 0.f ? delta_sum : nullptr, 0.0,
-                               threshold};
+                               threshold, eta_dev, lam};
       rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st)
               : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
                                             e2, st);
     } else {
       EpiProx e2{Y, codes, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
-                 fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0};
+                 fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0,
+                 eta_dev, lam};
       rc = launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1, e2,
                                        st);
     }
@@ -191,18 +203,20 @@ extern "C" size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n,
   const size_t fused = fused_workspace_bytes(b, n, s, precision);
   // bf16x3 falls back to the tiled bf16x3 contraction for shapes (or options)
   // the fused kernel does not cover: size for the larger of the two
-  if (precision == VTC_BF16X3) return fused > generic ? fused : generic;
+  if (precision == VTC_BF16X3 || precision == VTC_F16X3)
+    return fused > generic ? fused : generic;
   return fused;
 }
 
-extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
-                                 const float* initial_codes, float* codes,
-                                 int64_t b, int64_t n, int64_t s,
-                                 float stepsize, float sparsity_weight,
-                                 int num_iters, int variant, int threshold,
-                                 float early_stopping_epsilon, int precision,
-                                 void* workspace, size_t workspace_bytes,
-                                 int* iters_run, void* stream) {
+static int fc_ista_fista_impl(const float* images, const float* dictionary,
+                              const float* initial_codes, float* codes,
+                              int64_t b, int64_t n, int64_t s, float stepsize,
+                              const float* stepsize_dev,
+                              float sparsity_weight, int num_iters,
+                              int variant, int threshold,
+                              float early_stopping_epsilon, int precision,
+                              void* workspace, size_t workspace_bytes,
+                              int* iters_run, void* stream) {
   VTC_REQUIRE(b >= 0 && n > 0 && s > 0, "vtc_fc_ista_fista: bad sizes");
   VTC_REQUIRE(b == 0 || (images && dictionary && codes),
               "vtc_fc_ista_fista: null pointer");
@@ -213,27 +227,60 @@ extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
   VTC_REQUIRE(num_iters >= 1,
               "vtc_fc_ista_fista: num_iters must be >= 1 (the reference "
               "leaves `codes` unbound for 0)");
-  VTC_REQUIRE(precision >= VTC_F32 && precision <= VTC_BF16,
+  VTC_REQUIRE(precision >= VTC_F32 && precision <= VTC_F16X3,
               "vtc_fc_ista_fista: unknown precision %d", precision);
   if (iters_run) *iters_run = 0;
   if (b == 0) return VTC_OK;
-  // lambda*eta: the Python float is rounded to f32, then one f32 multiply
-  const float cutoff = sparsity_weight * stepsize;
   hipStream_t st = as_stream(stream);
   const bool fused_ok = early_stopping_epsilon < 0.f &&
+                        num_iters <= fused_max_iters() &&
                         fused_shape_supported(b, n, s, precision);
   if (precision == VTC_BF16 && !fused_ok) {
     set_error("vtc_fc_ista_fista: VTC_BF16 exists only as the fused kernel "
               "(n == 256, s in {256, 512, 1024}, no early stopping); use "
-              "VTC_BF16X3 or VTC_F32");
+              "VTC_F16X3, VTC_BF16X3 or VTC_F32");
     return VTC_ERR_UNSUPPORTED;
   }
   if (precision != VTC_F32 && fused_ok)
     return run_fused(images, dictionary, initial_codes, codes, b, n, s,
-                     stepsize, cutoff, num_iters, variant, threshold,
-                     precision, workspace, workspace_bytes, iters_run, st);
+                     stepsize, stepsize_dev, sparsity_weight, num_iters,
+                     variant, threshold, precision, workspace, workspace_bytes,
+                     iters_run, st);
+  // outside the fused kernel the split-operand modes both run on the tiled
+  // bf16 hi/lo contraction
   return run_generic(images, dictionary, initial_codes, codes, b, n, s,
-                     stepsize, cutoff, num_iters, variant, threshold,
-                     early_stopping_epsilon, precision == VTC_BF16X3,
-                     workspace, workspace_bytes, iters_run, st);
+                     stepsize, stepsize_dev, sparsity_weight, num_iters,
+                     variant, threshold, early_stopping_epsilon,
+                     precision != VTC_F32, workspace, workspace_bytes,
+                     iters_run, st);
+}
+
+extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,
+                                 const float* initial_codes, float* codes,
+                                 int64_t b, int64_t n, int64_t s,
+                                 float stepsize, float sparsity_weight,
+                                 int num_iters, int variant, int threshold,
+                                 float early_stopping_epsilon, int precision,
+                                 void* workspace, size_t workspace_bytes,
+                                 int* iters_run, void* stream) {
+  return fc_ista_fista_impl(images, dictionary, initial_codes, codes, b, n, s,
+                            stepsize, nullptr, sparsity_weight, num_iters,
+                            variant, threshold, early_stopping_epsilon,
+                            precision, workspace, workspace_bytes, iters_run,
+                            stream);
+}
+
+extern "C" int vtc_fc_ista_fista_dev(
+    const float* images, const float* dictionary, const float* initial_codes,
+    float* codes, int64_t b, int64_t n, int64_t s, const float* stepsize_dev,
+    float sparsity_weight, int num_iters, int variant, int threshold,
+    float early_stopping_epsilon, int precision, void* workspace,
+    size_t workspace_bytes, int* iters_run, void* stream) {
+  VTC_REQUIRE(stepsize_dev != nullptr,
+              "vtc_fc_ista_fista_dev: stepsize_dev is null");
+  return fc_ista_fista_impl(images, dictionary, initial_codes, codes, b, n, s,
+                            0.f, stepsize_dev, sparsity_weight, num_iters,
+                            variant, threshold, early_stopping_epsilon,
+                            precision, workspace, workspace_bytes, iters_run,
+                            stream);
 }

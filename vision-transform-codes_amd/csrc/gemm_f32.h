@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
   __shared__ __attribute__((aligned(16))) float As[2][kGemmBK][kGemmPitch];
   __shared__ __attribute__((aligned(16))) float Bs[2][kGemmBK][kGemmPitch];
 
+  resolve_epilogue(epi, 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;

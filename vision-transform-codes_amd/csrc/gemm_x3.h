@@ -84,6 +84,7 @@ template <class Epi>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   // [buf][A_hi, A_lo, B_hi, B_lo][128 rows][64 B]
   __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
+  resolve_epilogue(epi, 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
 template <class Epi>
 __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
   __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
+  resolve_epilogue(epi, 0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;

@@ -5,14 +5,17 @@
 //                                      convolutional variants)
 // once per plugin call, i.e. once per training step.  A full rocSOLVER
 // eigen-decomposition of a 256 x 256 matrix costs ~4 ms on MI355X (measured:
-// 5 % of a whole training step).  Only the top eigenvalue is needed, so this is a
-// single-workgroup Lanczos iteration with full re-orthogonalisation (the
-// Krylov basis lives in LDS), followed by 64-way sectioning on the tridiagonal
-// matrix with Sturm counts, in double precision, by one wave.  For n <= 128
-// the Krylov space is the whole space and the result is the exact top
-// eigenvalue up to rounding; for n <= 256, 128 steps converge to f32
+// 5 % of a whole training step).  Only the top eigenvalue is needed, so this is
+// a single-workgroup Lanczos iteration followed by sectioning on the
+// tridiagonal matrix with Sturm counts in double precision.  n <= 256: the
+// matrix lives in registers and the recurrence runs without
+// re-orthogonalisation (lanczos_lambda_max_kernel); 256 < n <= 1024: matrix
+// streamed from L2, Krylov basis in a global workspace, full
+// re-orthogonalisation (lanczos_large_kernel).  128 steps converge to f32
 // resolution on the spectra of interest (extreme eigenvalue, Kaniel-Paige).
 #include "common.h"
+
+#include <stdlib.h>
 
 namespace vtc {
 
@@ -20,7 +23,6 @@ constexpr int kLanczosMaxN = 256;
 constexpr int kLanczosMaxK = 128;
 
 constexpr int kLanczosThreads = 1024;   // 16 waves: 4 per SIMD
-constexpr int kLanczosParts = 4;        // row ranges of the mat-vec
 
 // sum over the first 256 threads (the vector components); every thread of the
 // block calls this and receives the result
@@ -76,145 +78,279 @@ __device__ double tridiagonal_lambda_max(const double* alpha,
   return 0.5 * (lo + hi);
 }
 
-// Thread layout: tid = part * 256 + t.  Component t of every vector belongs
-// to the threads (.., t); part 0 owns the Lanczos recurrences, parts 1..3 only
-// help with the mat-vec and the Gram-Schmidt sums.
-__global__ __launch_bounds__(kLanczosThreads) void lanczos_lambda_max_kernel(
-    const float* __restrict__ G, int n, int k, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* V = lds;                         // [k][n] Krylov basis
-  float* wl = V + (size_t)k * n;          // [n] work vector
-  float* coef = wl + n;                   // [k]
-  float* partial = coef + k;              // [parts][256]
-  __shared__ double red[4];
-  __shared__ double alpha[kLanczosMaxK];
-  __shared__ double beta[kLanczosMaxK];
-  __shared__ int steps_done;
-  __shared__ int stop_flag;
-  __shared__ double last_ritz;
-  const int tid = threadIdx.x;
-  const int t = tid & 255, part = tid >> 8;
-  const int lane = tid & 63, wave = tid >> 6;   // 16 waves
-  const bool on = t < n;
-  const bool owner = (part == 0) && on;
+// Sectioning for the n <= 256 kernel: the first four waves (one per SIMD) take
+// 256 points per round, the bracket shrinks 257x per round.  The Sturm count
+// comes from the three-term recurrence of the characteristic polynomials
+//   p_i = (alpha_i - x) p_{i-1} - beta_{i-1}^2 p_{i-2},
+// count(x) = number of sign changes along p_0..p_m, which has no division in
+// its dependency chain (an f64 divide is ~40 instructions; here a row costs
+// three f64 operations and an integer sign test).  Rows go in chunks of 8 --
+// their coefficients are fetched from LDS together, ahead of the chain -- and
+// the pair (p, p_prev) is rescaled by a power of two after every chunk so that
+// neither overflows.  alpha / beta2 are padded to a multiple of 8 rows with
+// (alpha = x-independent huge, beta2 = 0), which adds no sign change.  Every
+// thread of the block calls it and gets the same result.
+__device__ double tridiagonal_lambda_max_block(const double* alpha,
+                                               const double* beta2, int m,
+                                               double lo, double hi,
+                                               int rounds, int* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (!(hi == hi) || !(lo == lo)) return hi + lo;  // NaN propagates
+  // invariant: count(lo) < m <= count(hi), count(x) = #eigenvalues < x
+  for (int it = 0; it < rounds; ++it) {
+    const double step = (hi - lo) / 257.0;
+    if (wave < 4) {
+      const double x = lo + step * (double)(tid + 1);
+      double p_prev = 0.0, p = 1.0;     // p_{-1}, p_0
+      int below = 0;
+      for (int i0 = 0; i0 < m; i0 += 8) {
+        double al[8], b2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          al[q] = alpha[i0 + q];
+          b2[q] = (i0 + q > 0) ? beta2[i0 + q - 1] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (i0 + q < m) {
+            const double pn = fma(al[q] - x, p, -b2[q] * p_prev);
+            below += ((__double2hiint(pn) ^ __double2hiint(p)) >> 31) & 1;
+            p_prev = p;
+            p = pn;
+          }
+        }
+        const int e = ilogb(p);
+        p = ldexp(p, -e);
+        p_prev = ldexp(p_prev, -e);
+      }
+      // the threads whose point is above the top eigenvalue form a suffix
+      const unsigned long long above = __ballot(below == m);
+      if (lane == 0)
+        scratch[wave] =
+            above ? 64 * wave + (__ffsll((long long)above) - 1) : 256;
+    }
+    __syncthreads();
+    int first = 256;
+    for (int w = 0; w < 4; ++w) first = scratch[w] < first ? scratch[w] : first;
+    __syncthreads();
+    if (first == 256) {
+      lo = lo + step * 256.0;
+    } else {
+      const double new_hi = lo + step * (double)(first + 1);
+      if (first > 0) lo = lo + step * (double)first;
+      hi = new_hi;
+    }
+  }
+  return 0.5 * (lo + hi);
+}
 
-  // deterministic, generic start vector
-  float v = 0.f;
-  if (owner) {
-    unsigned x = (unsigned)t * 2654435761u + 12345u;
-    x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
-    v = 0.5f + (float)(x & 0xffff) / 65536.f;
+// Wave-wide sums on the DPP network (row shifts, then the two row broadcasts):
+// a handful of VALU instructions, where __shfl_xor goes through ds_bpermute at
+// an LDS round trip per stage -- this kernel is one workgroup running a chain
+// of dependent phases, so every such latency is exposed.  The total is
+// returned to all lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift(double v) {
+  const int lo = dpp_shift<CTRL, ROW_MASK>(__double2loint(v));
+  const int hi = dpp_shift<CTRL, ROW_MASK>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_wave_sum(double v) {
+  v += dpp_shift<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_shift<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_shift<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_shift<0x118, 0xf>(v);   // row_shr:8   lane 15 of a row = row sum
+  v += dpp_shift<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_shift<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// 1 / sqrt(x) in f64 from the f32 hardware estimate and two Newton steps (an
+// IEEE f64 sqrt or divide is a ~40-instruction dependent chain, and this
+// kernel would run three of them per Lanczos step on its critical path).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = (double)__frsqrt_rn((float)x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  r = r * (1.5 - 0.5 * x * r * r);
+  return r;
+}
+
+// n <= 256: the plain Lanczos three-term recurrence, 512 threads.
+//
+// Thread (half, t) keeps rows [128 half, 128 half + 128) of column t of the
+// symmetric matrix in REGISTERS for the whole iteration: the matrix is read
+// from memory once (a single workgroup re-streaming 256 KiB from L2 per step
+// was 2 us of every step).  One step = mat-vec (128 FMAs per thread against
+// broadcast LDS reads of v_j), alpha_j = <w, v_j>, w -= alpha_j v_j + beta_{j-1}
+// v_{j-1}, beta_j = ||w||: two barriers.  No re-orthogonalisation: only the TOP
+// eigenvalue is wanted, and the extreme Ritz value of the three-term
+// recurrence converges to it regardless of the loss of orthogonality among the
+// Lanczos vectors (which only breeds copies of already converged Ritz values);
+// what full re-orthogonalisation cost was five more block-wide phases per
+// step, each an LDS round trip plus a 16-wave barrier (measured: 6300 cycles
+// per step against 1500 here).  min(128, 2n) steps; measured against LAPACK on
+// dictionary Grams of every shape in tests/test_lipschitz_gpu.py: <= 4e-7.
+constexpr int kLzThreads = 512;
+
+template <bool STAMP>
+__global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
+    const float* __restrict__ G, int n, int k, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float vcur[256];  // b_{j-1} v_j
+  __shared__ float partial[2][256];
+  __shared__ double red_a[8], red_b[4];
+  __shared__ double alpha[kLanczosMaxK + 8];
+  __shared__ double beta[kLanczosMaxK + 8];
+  __shared__ double beta2[kLanczosMaxK + 8];
+  __shared__ int scratch[4];
+  unsigned long long st_t0 = 0, st_acc[4] = {0, 0, 0, 0};
+#define LZ_STAMP(slot)                                                   \
+  if (STAMP) {                                                           \
+    unsigned long long now_;                                             \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+    st_acc[slot] += now_ - st_t0;                                        \
+    st_t0 = now_;                                                        \
   }
-  double nrm = sqrt(block_sum_vec((double)v * v, red));
-  v = (float)(v / nrm);
-  float v_prev = 0.f;
-  double beta_prev = 0.0;
-  if (tid == 0) {
-    steps_done = k;
-    stop_flag = 0;
-    last_ritz = -1.0;
+  const int tid = threadIdx.x;
+  const int t = tid & 255, half = tid >> 8;
+  const int lane = tid & 63, wave = tid >> 6;   // 8 waves
+  const bool on = t < n;
+  const bool owner = (half == 0);
+
+  float g[128];
+#pragma unroll
+  for (int i = 0; i < 128; ++i) {
+    const int row = 128 * half + i;
+    // clamped address + select: no branch per element
+    const float x = G[(size_t)(row < n ? row : 0) * n + (on ? t : 0)];
+    g[i] = (on && row < n) ? x : 0.f;
   }
-  double tscale = 0.0;
-  const int rows_per_part = (n + kLanczosParts - 1) / kLanczosParts;
-  const int i0 = part * rows_per_part;
-  const int i1 = (i0 + rows_per_part < n) ? i0 + rows_per_part : n;
+
+  // deterministic, generic start vector (components past n are zero)
+  {
+    float v = 0.f;
+    if (on) {
+      unsigned x = (unsigned)t * 2654435761u + 12345u;
+      x ^= x >> 13; x *= 0x5bd1e995u; x ^= x >> 15;
+      v = 0.5f + (float)(x & 0xffff) / 65536.f;
+    }
+    const double ps = dpp_wave_sum(owner ? (double)v * v : 0.0);
+    if (owner && lane == 0) red_b[wave] = ps;
+    if (owner) vcur[t] = v;
+  }
+  if (tid < 8) {     // padding rows of the tridiagonal matrix (see the solver)
+    alpha[kLanczosMaxK + tid] = 0.0;
+    beta2[kLanczosMaxK + tid] = 0.0;
+  }
   __syncthreads();
+  double b2 = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+  double rb = fast_rsqrt(b2);
+  double b = b2 * rb;
+  double tscale = 0.0, beta_prev = 0.0;
+  float v_prev = 0.f;
+  int steps = 0;
+  if (STAMP)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
 
   for (int j = 0; j < k; ++j) {
-    if (owner) V[(size_t)j * n + t] = v;
-    __syncthreads();
-    // w = G v  (G symmetric: "column" t is contiguous across threads); each
-    // part sums its row range with 4 independent accumulators
+    const float inv_b = (float)rb;
+    const float vt = vcur[t] * inv_b;        // component t of v_j
+    // ---- [A] w = G v_j: this thread's 128 rows of column t, and this wave's
+    // share of <w, v_j>
     {
-      const float* vj = V + (size_t)j * n;
+      const float4* v4 = reinterpret_cast<const float4*>(vcur + 128 * half);
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (on) {
-        int i = i0;
-        for (; i + 3 < i1; i += 4) {
-          a0 = fmaf(G[(size_t)(i + 0) * n + t], vj[i + 0], a0);
-          a1 = fmaf(G[(size_t)(i + 1) * n + t], vj[i + 1], a1);
-          a2 = fmaf(G[(size_t)(i + 2) * n + t], vj[i + 2], a2);
-          a3 = fmaf(G[(size_t)(i + 3) * n + t], vj[i + 3], a3);
+      // the 32 broadcast reads in 4 batches of 8, each batch issued before the
+      // FMAs of the previous one (left alone, hipcc keeps two reads in flight
+      // and the loop runs at LDS latency: 2200 cycles instead of ~1000)
+      float4 xa[8], xb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] = v4[q];
+#pragma unroll
+      for (int batch = 0; batch < 4; ++batch) {
+        if (batch + 1 < 4) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (batch & 1) xa[q] = v4[8 * (batch + 1) + q];
+            else xb[q] = v4[8 * (batch + 1) + q];
+          }
         }
-        for (; i < i1; ++i) a0 = fmaf(G[(size_t)i * n + t], vj[i], a0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 x = (batch & 1) ? xb[q] : xa[q];
+          const int i = 8 * batch + q;
+          a0 = fmaf(g[4 * i + 0], x.x, a0);
+          a1 = fmaf(g[4 * i + 1], x.y, a1);
+          a2 = fmaf(g[4 * i + 2], x.z, a2);
+          a3 = fmaf(g[4 * i + 3], x.w, a3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      partial[part * 256 + t] = (a0 + a1) + (a2 + a3);
+      const float pw = ((a0 + a1) + (a2 + a3)) * inv_b;
+      partial[half][t] = pw;
+      const double pa = dpp_wave_sum((double)pw * vt);
+      if (lane == 0) red_a[wave] = pa;
     }
     __syncthreads();
-    float w = 0.f;
-    if (owner)
-      w = (partial[t] + partial[256 + t]) + (partial[512 + t] + partial[768 + t]);
-    const double a = block_sum_vec(owner ? (double)w * v : 0.0, red);
-    if (owner) {
-      w = w - (float)a * v - (float)beta_prev * v_prev;
-      wl[t] = w;
-    }
-    __syncthreads();
-    // full re-orthogonalisation against V[0..j]: coefficients by 16 waves,
-    // correction split over the 4 parts
-    for (int i = wave; i <= j; i += kLanczosThreads / 64) {
-      float p = 0.f;
-      for (int c = lane; c < n; c += 64) p = fmaf(V[(size_t)i * n + c], wl[c], p);
-      p = wave_sum(p);
-      if (lane == 0) coef[i] = p;
-    }
-    __syncthreads();
+    LZ_STAMP(0)
+    // ---- [B] w -= alpha_j v_j + beta_{j-1} v_{j-1};  ||w||^2
+    float w = partial[0][t] + partial[1][t];
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += red_a[u];
+    w = w - (float)a * vt - (float)beta_prev * v_prev;
     {
-      float corr = 0.f;
-      if (on)
-        for (int i = part; i <= j; i += kLanczosParts)
-          corr = fmaf(coef[i], V[(size_t)i * n + t], corr);
-      partial[part * 256 + t] = corr;
+      const double pb = dpp_wave_sum(owner ? (double)w * w : 0.0);
+      if (owner && lane == 0) red_b[wave] = pb;
+      if (owner) vcur[t] = w;      // every mat-vec read of v_j is behind us
     }
+    v_prev = vt;
     __syncthreads();
-    if (owner)
-      w -= (partial[t] + partial[256 + t]) + (partial[512 + t] + partial[768 + t]);
-    const double b = sqrt(block_sum_vec(owner ? (double)w * w : 0.0, red));
+    LZ_STAMP(1)
+    b2 = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+    rb = fast_rsqrt(b2);
+    b = b2 * rb;                      // 0 * inf = NaN for b2 == 0: stops below
     if (tid == 0) {
       alpha[j] = a;
-      beta[j] = b;
+      beta[j] = b2 > 0.0 ? b : 0.0;
+      beta2[j] = b2;
     }
+    steps = j + 1;
     tscale = fmax(tscale, fmax(fabs(a), b));
     // Krylov space exhausted (rank-deficient Gram, invariant subspace) or a
     // NaN: what is left of w is rounding noise -- normalising it would feed
     // amplified garbage into the recurrence.  The tridiagonal matrix so far
     // already holds the spectrum of the reachable space.
-    if (!(b > 1e-5 * tscale)) {
-      if (tid == 0) steps_done = j + 1;
-      break;
-    }
-    // every 8 steps: has the top Ritz value stopped moving?  (it grows
-    // monotonically with the Krylov dimension)
-    if ((j & 7) == 7) {
-      __syncthreads();                 // alpha[j], beta[j] visible to wave 0
-      if (wave == 0) {
-        const double ritz = tridiagonal_lambda_max(alpha, beta, j + 1);
-        if (tid == 0) {
-          stop_flag = (last_ritz > 0.0 &&
-                       fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
-          last_ritz = ritz;
-        }
-      }
-      __syncthreads();
-      if (stop_flag) {
-        if (tid == 0) steps_done = j + 1;
-        break;
-      }
-    }
-    v_prev = v;
-    v = (float)(w / b);
+    if (!(b > 1e-5 * tscale)) break;
     beta_prev = b;
   }
   __syncthreads();
-
-  if (wave == 0) {
-    const double lambda = tridiagonal_lambda_max(alpha, beta, steps_done);
-    const float lf = (float)lambda;
-    if (tid == 0) {
-      out[0] = lf;
-      out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
-    }
+  double lo = alpha[0], hi = alpha[0];
+  for (int i = 0; i < steps; ++i) {
+    const double off = (i > 0 ? beta[i - 1] : 0.0) +
+                       (i + 1 < steps ? beta[i] : 0.0);
+    lo = fmin(lo, alpha[i] - off);
+    hi = fmax(hi, alpha[i] + off);
   }
+  LZ_STAMP(2)
+  // 257^4 = 4.4e9 sections of a bracket a few lambda wide: below f32 resolution
+  const double lambda =
+      tridiagonal_lambda_max_block(alpha, beta2, steps, lo, hi, 4, scratch);
+  const float lf = (float)lambda;
+  LZ_STAMP(3)
+  if (tid == 0) {
+    out[0] = lf;
+    out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+    if (STAMP)
+      for (int q = 0; q < 4; ++q) out[2 + q] = (float)st_acc[q];
+  }
+#undef LZ_STAMP
 }
 
 // ---------------------------------------------------------------- n > 256
@@ -380,17 +516,18 @@ extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
     VTC_LAUNCH_CHECK();
     return VTC_OK;
   }
-  const size_t lds =
-      ((size_t)k * n + n + k + kLanczosParts * 256) * sizeof(float);
-  static unsigned long long configured = 0;
-  if (first_use_on_this_device(&configured)) {
-    VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(lanczos_lambda_max_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  }
-  hipLaunchKernelGGL(lanczos_lambda_max_kernel, dim3(1),
-                     dim3(kLanczosThreads), lds,
-                     as_stream(stream), symmetric, (int)n, k, out);
+  // diagnostic: VTC_LANCZOS_STAMPS=1 and an `out` of 6 floats -> cycles per
+  // phase in out[2..5] (A mat-vec, B update, bounds, tridiagonal solve)
+  static const bool stamps = getenv("VTC_LANCZOS_STAMPS") != nullptr;
+  const int k_small = (int)(2 * n < kLanczosMaxK ? 2 * n : kLanczosMaxK);
+  if (stamps)
+    hipLaunchKernelGGL(lanczos_lambda_max_kernel<true>, dim3(1),
+                       dim3(kLzThreads), 0, as_stream(stream), symmetric,
+                       (int)n, k_small, out);
+  else
+    hipLaunchKernelGGL(lanczos_lambda_max_kernel<false>, dim3(1),
+                       dim3(kLzThreads), 0, as_stream(stream), symmetric,
+                       (int)n, k_small, out);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }

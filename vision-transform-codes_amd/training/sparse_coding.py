@@ -13,8 +13,9 @@ SummaryWriter), the latter raises NotImplementedError if requested.
 
 Data parallelism (not in the reference): when vtc_hip.parallel is enabled each
 rank feeds its own shard of every batch; inference is local, the dictionary
-gradient and the code energy are summed over ranks with one RCCL all-reduce
-each, and all ranks apply the same update.
+gradient and the code energy are summed over ranks with ONE RCCL all-reduce
+per update iteration (the energy rides in the gradient's buffer), and all
+ranks apply the same update.
 """
 import ctypes
 import pickle
@@ -160,10 +161,16 @@ class TrainingStep(object):
     vtc_hip.check(lib.vtc_code_energy(
         vtc_hip.ptr(codes), b, s, positions, vtc_hip.ptr(energy),
         vtc_hip.ptr(ws), ws.numel(), stream), 'vtc_code_energy')
-    parallel.all_reduce_sum_(energy)
-    vtc_hip.check(lib.vtc_hessian_ema(
-        vtc_hip.ptr(self.hessian_diag), vtc_hip.ptr(energy),
-        parallel.global_batch(b, device), s, stream), 'vtc_hessian_ema')
+    total = parallel.global_batch(b, device)
+    hessian = self.hessian_diag
+
+    def ema():
+      vtc_hip.check(lib.vtc_hessian_ema(
+          vtc_hip.ptr(hessian), vtc_hip.ptr(energy), total, s, stream),
+          'vtc_hessian_ema')
+    # data parallel: the s floats ride on the gradient's all-reduce (first
+    # update iteration of the plugin) and the EMA runs right behind it
+    parallel.defer(energy, ema)
 
   def update_dictionary(self, batch_images, batch_codes):
     """Keyword call into the update plugin (sparse_coding.py:142-168)."""
@@ -186,6 +193,7 @@ class TrainingStep(object):
       kwargs.update({'group_assignments': self.groups,
                      'alignment_penalty': self.alignment_penalty})
     self.dict_update.run(**kwargs)
+    parallel.flush_deferred()
 
   def __call__(self, batch_images):
     codes = self.infer_codes(batch_images)
@@ -370,4 +378,7 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
       step(batch_images)
       total_iter_idx += 1
     print("Epoch", epoch_idx + 1, "finished")
+  # the sync-free inference path reports a failed eigen-solve late: collect
+  # whatever is still pending before handing the dictionary back
+  vtc_hip.poll_spectrum_checks(block=True)
   return step

@@ -5,7 +5,10 @@ PyTorch is used here for what it is good at on ROCm -- device memory, the
 current HIP stream, torch.distributed -- and nothing else: every arithmetic
 step of the plugins goes through the C entry points below, on raw device
 pointers.  There is deliberately no CPU or eager-PyTorch fallback: if the
-library is missing or a tensor is not on the GPU the call raises.
+library is missing or a tensor is not on the GPU the call raises.  (One
+exception, stated where it lives: Gram matrices beyond 1024 x 1024 -- none of
+the path's configurations -- take torch.linalg.eigvalsh for the Lipschitz
+constant, see stepsize_from_gram.)
 """
 import ctypes
 import os
@@ -19,9 +22,9 @@ LIBRARY_PATH = _PKG_ROOT / 'libvtc_hip.so'
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP = range(5)
 ISTA, FISTA = 0, 1
 SOFT, SOFT_NONNEG, HARD, HARD_NONNEG = range(4)
-F32, BF16X3, BF16 = range(3)
-PRECISIONS = {'f32': F32, 'bf16x3': BF16X3, 'bf16': BF16}
-ABI_VERSION = 2   # VTC_ABI_VERSION of include/vtc_hip.h this binding matches
+F32, BF16X3, BF16, F16X3 = range(4)
+PRECISIONS = {'f32': F32, 'bf16x3': BF16X3, 'bf16': BF16, 'f16x3': F16X3}
+ABI_VERSION = 3   # VTC_ABI_VERSION of include/vtc_hip.h this binding matches
 
 _lib = None
 
@@ -61,6 +64,9 @@ SIGNATURES = {
     'vtc_fc_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                  _f32, _i32, _i32, _i32, _f32, _i32, _vp, _sz,
                                  ctypes.POINTER(_i32), _vp]),
+    'vtc_fc_ista_fista_dev': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp,
+                                     _f32, _i32, _i32, _i32, _f32, _i32, _vp,
+                                     _sz, ctypes.POINTER(_i32), _vp]),
     'vtc_group_gather_rows': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     'vtc_group_gather_cols': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                      _vp]),
@@ -201,9 +207,10 @@ _default_precision = os.environ.get('VTC_PRECISION', 'auto')
 
 
 def set_default_precision(name):
-  """'auto' | 'f32' | 'bf16x3' | 'bf16'.  'auto' picks bf16x3 (float32-level
-  accuracy on the bf16 matrix pipe) when the fused kernel supports the shape
-  and exact-f32 MFMA otherwise."""
+  """'auto' | 'f32' | 'f16x3' | 'bf16x3' | 'bf16'.  'auto' picks f16x3 (an
+  f16 hi/lo split, three products on the 16-bit matrix pipe: float32-level
+  accuracy) when the fused kernel supports the shape, bf16x3 tiles for other
+  large problems and exact-f32 MFMA otherwise."""
   global _default_precision
   assert name in ('auto',) + tuple(PRECISIONS)
   _default_precision = name
@@ -257,27 +264,88 @@ def gram(matrix, transpose_a):
 
 LANCZOS_MAX_N = 1024
 _use_device_eigensolver = os.environ.get('VTC_EIGEN', 'lanczos') != 'library'
+# Deferred error channel of the sync-free path: [lambda_max, eta] of every
+# device-side eigen-solve is copied (8 bytes, asynchronously) to pinned host
+# memory and looked at once its event has completed -- at the next plugin
+# call, never by waiting.  A non-finite spectrum then raises the reference's
+# RuntimeError (ista_fista.py:75-79) one call late instead of stalling every
+# step behind a device-to-host read.  Set to False to drop the copy as well.
+spectrum_check = os.environ.get('VTC_SPECTRUM_CHECK', '1') != '0'
+_pending_spectra = []
+
+
+def _report_bad_spectrum(dictionary_for_message):
+  print('the eigen-solve threw an exception. Likely due to one of the',
+        'dictionary elements overflowing. The norm of each dictionary',
+        'element is')
+  flat = dictionary_for_message.reshape(dictionary_for_message.shape[0], -1)
+  print(torch.norm(flat, dim=1, p=2))
+  raise RuntimeError()
+
+
+def poll_spectrum_checks(block=False):
+  """Look at the eigen-solves whose results have reached the host (all of
+  them when block=True); raise like the reference if one was not finite."""
+  while _pending_spectra:
+    event, pinned, dictionary = _pending_spectra[0]
+    if block:
+      event.synchronize()
+    elif not event.query():
+      return
+    _pending_spectra.pop(0)
+    lam = float(pinned[0])
+    if not (lam == lam) or lam in (float('inf'), float('-inf')):
+      del _pending_spectra[:]
+      _report_bad_spectrum(dictionary)
+
+
+def lambda_max_device(gram_matrix):
+  """[lambda_max, 1 / lambda_max] of a symmetric (n, n) device matrix,
+  n <= 1024, as a 2-element device tensor (vtc_lambda_max: one small HIP
+  kernel, Lanczos + Sturm counts).  Nothing comes back to the host."""
+  lib = load_library()
+  n = gram_matrix.shape[0]
+  out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
+  ws = workspace(lib.vtc_lambda_max_workspace_bytes(n), gram_matrix.device)
+  check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out), ptr(ws),
+                           ws.numel(), current_stream(gram_matrix.device)),
+        'vtc_lambda_max')
+  return out
+
+
+def device_stepsize_available(n):
+  return _use_device_eigensolver and n <= LANCZOS_MAX_N
+
+
+def stepsize_on_device(gram_matrix, dictionary_for_message):
+  """eta = 1 / lambda_max(gram) as a 1-element DEVICE tensor, the way the
+  reference keeps it (ista_fista.py:80): no host synchronisation.  Failure
+  of the eigen-solve surfaces through poll_spectrum_checks()."""
+  poll_spectrum_checks()
+  out = lambda_max_device(gram_matrix)
+  if spectrum_check:
+    pinned = torch.empty(2, dtype=torch.float32, pin_memory=True)
+    pinned.copy_(out, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record(torch.cuda.current_stream(gram_matrix.device))
+    _pending_spectra.append((event, pinned, dictionary_for_message))
+  return out[1:2]
 
 
 def stepsize_from_gram(gram_matrix, dictionary_for_message):
-  """eta = 1 / lambda_max(gram) as a Python float.
+  """eta = 1 / lambda_max(gram) as a Python float (one host sync).
 
-  n <= 1024: vtc_lambda_max (one small HIP kernel: Lanczos + Sturm counts).
-  Otherwise torch.linalg.eigvalsh, the successor of the torch.symeig the
-  reference calls (removed in torch >= 2).  Mirrors the reference's error
-  path: on failure print the kernel norms and raise a bare RuntimeError
+  n <= 1024: vtc_lambda_max.  Otherwise torch.linalg.eigvalsh, the successor
+  of the torch.symeig the reference calls (removed in torch >= 2) -- the one
+  place a library routine stands in for a kernel of this engine; no
+  configuration of the path produces such a matrix (patches beyond 32 x 32 or
+  more than 1024 convolution kernels).  Mirrors the reference's error path:
+  on failure print the kernel norms and raise a bare RuntimeError
   (ista_fista.py:75-79)."""
   n = gram_matrix.shape[0]
   try:
-    if _use_device_eigensolver and n <= LANCZOS_MAX_N:
-      lib = load_library()
-      out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
-      ws = workspace(lib.vtc_lambda_max_workspace_bytes(n),
-                     gram_matrix.device)
-      check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out), ptr(ws),
-                               ws.numel(),
-                               current_stream(gram_matrix.device)),
-            'vtc_lambda_max')
+    if device_stepsize_available(n):
+      out = lambda_max_device(gram_matrix)
       lipschitz_constant, stepsize = [float(v) for v in out.tolist()]
       if not (lipschitz_constant == lipschitz_constant) or (
           lipschitz_constant in (float('inf'), float('-inf'))):
@@ -285,10 +353,5 @@ def stepsize_from_gram(gram_matrix, dictionary_for_message):
       return stepsize
     lipschitz_constant = torch.linalg.eigvalsh(gram_matrix, UPLO='U')[-1]
   except RuntimeError:
-    print('the eigen-solve threw an exception. Likely due to one of the',
-          'dictionary elements overflowing. The norm of each dictionary',
-          'element is')
-    flat = dictionary_for_message.reshape(dictionary_for_message.shape[0], -1)
-    print(torch.norm(flat, dim=1, p=2))
-    raise RuntimeError()
+    _report_bad_spectrum(dictionary_for_message)
   return float(1. / lipschitz_constant)
