@@ -120,7 +120,9 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
                 s in (256, 512, 1024) and fused_available())
     tiled_ok = (n % 4 == 0 and s % 4 == 0 and b * s >= (1 << 22) and
                 fused_available())
-    if fused_ok:
+    streamed_ok = (early_stopping_epsilon is None and n == 256 and
+                   s > 1024 and s % 256 == 0 and fused_available())
+    if fused_ok or streamed_ok:
       return vtc_hip.F16X3
     return vtc_hip.BF16X3 if tiled_ok else vtc_hip.F32
   return vtc_hip.PRECISIONS[name]

@@ -80,8 +80,16 @@ def run(images, dictionary, group_assignments, sparsity_weight,
   name = precision if precision is not None else (
       vtc_hip.get_default_precision())
   if name == 'auto':
-    name = 'bf16x3' if (slots >= 1024 and slots % 4 == 0 and n % 4 == 0) else (
-        'f32')
+    # 16x16 patches, groups of 1/2/4/8 slots: the fused persistent kernel with
+    # streamed state (f16 hi/lo split, float32-level results); other large
+    # problems: bf16x3 tiles; small ones: exact f32
+    if (n == 256 and slots % 256 == 0 and m in (1, 2, 4, 8) and
+        early_stopping_epsilon is None):
+      name = 'f16x3'
+    elif slots >= 1024 and slots % 4 == 0 and n % 4 == 0:
+      name = 'bf16x3'
+    else:
+      name = 'f32'
   if name == 'bf16':
     raise NotImplementedError('subspace inference has no bf16 fast mode')
   vtc_hip.check(lib.vtc_subspace_ista_fista(

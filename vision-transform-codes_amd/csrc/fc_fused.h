@@ -15,8 +15,10 @@ int run_fused(const float* images, const float* dictionary,
               float sparsity_weight, int num_iters, int variant,
               int threshold, int precision, void* workspace,
               size_t workspace_bytes, int* iters_run, hipStream_t st);
-// iterations per call the fused kernel's momentum table covers
+// iterations per call the fused kernels' momentum table covers, and the table
+// itself (one copy per device, created on first use there)
 int fused_max_iters();
+const float* fista_beta_table_on_this_device();
 
 // host-side FISTA momentum schedule (fc_inference.hip)
 void fista_betas(int num_iters, std::vector<float>* out);

@@ -15,6 +15,7 @@
 #include "gemm_x3.h"
 #include "epi_prox.h"
 #include "fc_fused.h"
+#include "fused_stream.h"
 
 #include <math.h>
 #include <vector>
@@ -203,8 +204,13 @@ extern "C" size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n,
   const size_t fused = fused_workspace_bytes(b, n, s, precision);
   // bf16x3 falls back to the tiled bf16x3 contraction for shapes (or options)
   // the fused kernel does not cover: size for the larger of the two
-  if (precision == VTC_BF16X3 || precision == VTC_F16X3)
-    return fused > generic ? fused : generic;
+  if (precision == VTC_BF16X3 || precision == VTC_F16X3) {
+    const size_t streamed = stream_shape_supported(b, n, s, 1, precision)
+                                ? stream_workspace_bytes(b, n, s, precision)
+                                : 0;
+    const size_t most = fused > generic ? fused : generic;
+    return most > streamed ? most : streamed;
+  }
   return fused;
 }
 
@@ -246,8 +252,17 @@ static int fc_ista_fista_impl(const float* images, const float* dictionary,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
                      variant, threshold, precision, workspace, workspace_bytes,
                      iters_run, st);
-  // outside the fused kernel the split-operand modes both run on the tiled
-  // bf16 hi/lo contraction
+  // 16x16 patches against more atoms than the on-chip state holds: the fused
+  // kernel with streamed state
+  if (precision != VTC_F32 && precision != VTC_BF16 &&
+      early_stopping_epsilon < 0.f && num_iters <= fused_max_iters() &&
+      stream_shape_supported(b, n, s, 1, precision))
+    return run_stream(images, dictionary, initial_codes, codes, b, n, s, 1,
+                      stepsize, stepsize_dev, sparsity_weight, num_iters,
+                      variant, threshold, precision, workspace,
+                      workspace_bytes, iters_run, st);
+  // elsewhere the split-operand modes both run on the tiled bf16 hi/lo
+  // contraction
   return run_generic(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
                      variant, threshold, early_stopping_epsilon,

@@ -14,6 +14,7 @@
 // the exact-f32 path, P is written by the product and one of the proximal
 // kernels below follows.
 #include "common.h"
+#include "fused_stream.h"
 #include "gemm_f32.h"
 #include "gemm_x3.h"
 #include "epi_prox.h"
@@ -320,7 +321,12 @@ extern "C" size_t vtc_subspace_ista_fista_workspace_bytes(int64_t b, int64_t n,
                                                           int64_t groups,
                                                           int64_t m) {
   if (b <= 0 || n <= 0 || groups <= 0 || m <= 0) return 256;
-  return subspace_ws_bytes(b, n, groups * m);
+  const size_t tiled = subspace_ws_bytes(b, n, groups * m);
+  const size_t streamed =
+      stream_shape_supported(b, n, groups * m, m, VTC_F16X3)
+          ? stream_workspace_bytes(b, n, groups * m, VTC_F16X3)
+          : 0;
+  return tiled > streamed ? tiled : streamed;
 }
 
 extern "C" int vtc_subspace_ista_fista(
@@ -331,9 +337,10 @@ extern "C" int vtc_subspace_ista_fista(
     void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
   VTC_REQUIRE(b == 0 || (images && grouped_dictionary && grouped_codes),
               "vtc_subspace_ista_fista: null pointer");
-  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
-              "vtc_subspace_ista_fista: precision must be VTC_F32 or "
-              "VTC_BF16X3");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3 ||
+                  precision == VTC_F16X3,
+              "vtc_subspace_ista_fista: precision must be VTC_F32, "
+              "VTC_BF16X3 or VTC_F16X3");
   VTC_REQUIRE(b >= 0 && n > 0 && groups > 0 && m > 0,
               "vtc_subspace_ista_fista: bad sizes");
   VTC_REQUIRE(variant == VTC_ISTA || variant == VTC_FISTA,
@@ -342,6 +349,17 @@ extern "C" int vtc_subspace_ista_fista(
   if (iters_run) *iters_run = 0;
   if (b == 0) return VTC_OK;
   const int64_t slots = groups * m;
+  // 16x16 patches, groups of 1/2/4/8 slots, no early stopping: the fused
+  // persistent kernel with streamed state (fused_stream.hip)
+  if (precision != VTC_F32 && early_stopping_epsilon < 0.f &&
+      num_iters <= fused_max_iters_for_stream() &&
+      stream_shape_supported(b, n, slots, m, precision))
+    return run_stream(images, grouped_dictionary, initial_grouped,
+                      grouped_codes, b, n, slots, m, stepsize, nullptr,
+                      sparsity_weight, num_iters, variant, VTC_SOFT, precision,
+                      workspace, workspace_bytes, iters_run,
+                      as_stream(stream));
+  if (precision == VTC_F16X3) precision = VTC_BF16X3;   // tiled path
   if (!workspace || workspace_bytes < subspace_ws_bytes(b, n, slots)) {
     set_error("vtc_subspace_ista_fista: workspace too small");
     return VTC_ERR_WORKSPACE;
