@@ -49,7 +49,7 @@ constexpr int kSYxRow = 272;            // Y' exchange row: 256 B + 16 B pad
 constexpr int kSRxRow = 528;            // R exchange row: 512 B + 16 B pad
 constexpr int kSYxPart = 32 * kSYxRow;  // 8704
 constexpr int kSRxPart = 32 * kSRxRow;  // 16896
-constexpr int kSLds = 2 * 2 * kSYxPart + 2 * kSRxPart + 512;
+constexpr int kSLds = 2 * 2 * kSYxPart + 2 * kSRxPart + 1024;
 constexpr int kSRing = 8;
 
 struct StreamParams {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
   char* Yx = smem;
   char* Rx = Yx + 2 * NP * kSYxPart;
   float* Stat = reinterpret_cast<float*>(Rx + NP * kSRxPart);
-  char* Slots = reinterpret_cast<char*>(Stat) + 512;
+  char* Slots = reinterpret_cast<char*>(Stat) + 1024;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -187,8 +187,7 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
       if (phase_nz) __syncthreads();
       __syncthreads();
     }
-    if (F16) __syncthreads();                // exchange_r
-    __syncthreads();
+    __syncthreads();                         // exchange_r
     // state buffers as buffer resources: lane * 16 in the vector offset, the
     // tile in the scalar offset (bytes; one workgroup's share is < 4 GiB)
     const size_t wg_bytes = (size_t)nph * 4 * 4 * 1024;
@@ -289,8 +288,7 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
         if (q + 2 < nph) dma_phase(q + 2);
         prefetch_dict(q);
       }
-      if (F16) __syncthreads();              // exchange_r
-      __syncthreads();
+      __syncthreads();                       // exchange_r
       which_cur ^= 1;
     }
     return;
@@ -365,8 +363,8 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
     int e2 = 0;
     if (m2 > 0.f && m2 < __builtin_inff()) e2 = ilogbf(m2) >> 1;
     e2 = e2 < -60 ? -60 : (e2 > 60 ? 60 : e2);
-    sigma_y = ldexpf(1.f, 11 - e2);
-    inv_sigma_y = ldexpf(1.f, e2 - 11);
+    sigma_y = ldexpf(1.f, 8 - e2);
+    inv_sigma_y = ldexpf(1.f, e2 - 8);
     sigma_d = P.dscale[0];
     inv_sigma_d = P.dscale[1];
     // the stored iterates move to the scaled units as well
@@ -391,6 +389,7 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
     cutoff_l = cutoff_l * sigma_y;
   }
   const float r_scale = F16 ? 2.f * inv_sigma_d : 1.f;
+  int xr_calls = 0;
 
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
@@ -487,13 +486,18 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(v[nb][e]));
       m = fmaxf(m, __shfl_xor(m, 32, 64));
-      if (h == 0) Stat[w * 32 + r] = m;
-      __syncthreads();
-      const float Mx = fmaxf(fmaxf(Stat[r], Stat[32 + r]),
-                             fmaxf(Stat[64 + r], Stat[96 + r]));
+      // the decision uses the maxima all four waves left at the PREVIOUS call
+      // (visible since that call's closing barrier): no barrier of its own
       float f = 1.f;
-      if (Mx > 8192.f && Mx < __builtin_inff())
-        f = ldexpf(1.f, 12 - ilogbf(Mx));
+      if (xr_calls > 0) {
+        const float* prev = Stat + ((xr_calls - 1) & 1) * 128;
+        const float Mx = fmaxf(fmaxf(prev[r], prev[32 + r]),
+                               fmaxf(prev[64 + r], prev[96 + r]));
+        if (Mx > 2048.f && Mx < __builtin_inff())
+          f = ldexpf(1.f, 9 - ilogbf(Mx));
+      }
+      if (h == 0) Stat[(xr_calls & 1) * 128 + w * 32 + r] = m * f;
+      ++xr_calls;
       if (__any(f != 1.f)) {
         for (int q = 0; q < nph; ++q)
           for (int g = 0; g < 4; ++g)
