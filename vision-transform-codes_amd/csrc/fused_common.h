@@ -136,15 +136,11 @@ template <bool F16, int NP>
 __device__ __forceinline__ void split4(const float (&v)[4], uint2* hi_out,
                                        uint2* lo_out) {
   if (F16) {
-    // hi = v with the low 13 significand bits cleared (11 significant bits,
-    // exactly representable in f16 at these magnitudes), lo = v - hi exactly:
-    // a mask and a subtract instead of a conversion to f16 and back
     f16x4 hi, lo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float h32 = __uint_as_float(__float_as_uint(v[k]) & 0xFFFFE000u);
-      hi[k] = (_Float16)h32;
-      if (NP == 2) lo[k] = (_Float16)(v[k] - h32);
+      hi[k] = (_Float16)v[k];
+      if (NP == 2) lo[k] = (_Float16)(v[k] - (float)hi[k]);
     }
     *hi_out = __builtin_bit_cast(uint2, hi);
     if (NP == 2) *lo_out = __builtin_bit_cast(uint2, lo);
