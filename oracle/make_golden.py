@@ -502,6 +502,78 @@ def make_trainer_c2(ref):
   np.savez_compressed(GOLDEN / 'trainer_c2.npz', **out)
 
 
+def reset_prune_cases():
+  """(tag, filter_type, filter_params without groups, action, numpy seed,
+  torch seed) behind tests/golden/reset_prune.npz."""
+  return [
+      ('random_reset', 'random', {'num_to_modify': 5}, 'reset', 3, 4),
+      ('random_prune', 'random', {'num_to_modify': 4}, 'prune', 5, 6),
+      ('cos_reset', 'cosine_sim_threshold',
+       {'cue_user': False, 'only_sim_within_group': False, 'threshold': 0.9},
+       'reset', 7, 8),
+      ('cos_prune', 'cosine_sim_threshold',
+       {'cue_user': False, 'only_sim_within_group': False, 'threshold': 0.9},
+       'prune', 9, 10),
+      ('cos_group_prune', 'cosine_sim_threshold',
+       {'cue_user': False, 'only_sim_within_group': True, 'threshold': 0.9},
+       'prune', 11, 12),
+      ('cos_group_reset', 'cosine_sim_threshold',
+       {'cue_user': False, 'only_sim_within_group': True, 'threshold': 0.9},
+       'reset', 13, 14),
+      ('nonuniform_reset', 'nonuniformity_within_group',
+       {'num_gc_in_average': 6}, 'reset', 15, 16)]
+
+
+def reset_prune_inputs():
+  """A 32-atom dictionary in 8 groups of 4 with three near-duplicate pairs
+  (two of them inside a group), and codes whose phase inside two groups is
+  concentrated on one direction."""
+  rs = np.random.RandomState(70)
+  D = rs.randn(32, 16).astype(np.float32)
+  D[5] = D[4] + 0.05 * rs.randn(16).astype(np.float32)      # within group 1
+  D[14] = -D[13] + 0.05 * rs.randn(16).astype(np.float32)   # within group 3
+  D[30] = D[2] + 0.05 * rs.randn(16).astype(np.float32)     # across groups
+  D /= np.linalg.norm(D, axis=1, keepdims=True)
+  groups = [list(range(4 * g, 4 * g + 4)) for g in range(8)]
+  C = np.zeros((600, 32), np.float32)
+  for g in range(8):
+    rows = rs.rand(600) < 0.5
+    C[np.ix_(rows, groups[g])] = rs.randn(int(rows.sum()), 4)
+  for g in (2, 6):                                # lopsided phases
+    C[:, groups[g][1:]] *= 0.02
+  return D, groups, C
+
+
+def make_reset_prune(ref):
+  """f4: the reference's own reset_or_prune_dict_elements on CPU tensors, every
+  non-interactive mode; numpy and torch seeded per case."""
+  D0, groups0, C = reset_prune_inputs()
+  out = {'dictionary': D0, 'codes': C}
+  for tag, f_type, f_params, action, np_seed, torch_seed in reset_prune_cases():
+    results = []
+    for fn in (ref.trainer.reset_or_prune_dict_elements,
+               sc_oracle.reset_or_prune):
+      groups = [list(g) for g in groups0]
+      params = dict(f_params)
+      params.update({'group_assignments': groups,
+                     'coding_mode': 'fully-connected'})
+      np.random.seed(np_seed)
+      torch.manual_seed(torch_seed)
+      Dn, rows = fn(T(D0.copy()), T(C), f_type, params, action)
+      results.append((Dn, np.asarray(rows), groups))
+    (Dr, rows_r, groups_r), (Dm, rows_m, groups_m) = results
+    assert np.array_equal(rows_r, rows_m) and groups_r == groups_m, tag
+    report('reset_prune ' + tag, Dm, Dr)
+    print('      affected', rows_r.tolist())
+    assert len(rows_r) > 0, tag
+    out[tag + '_dictionary'] = Dr.numpy()
+    out[tag + '_affected'] = rows_r.astype(np.int64)
+    out[tag + '_group_sizes'] = np.array([len(g) for g in groups_r], np.int64)
+    out[tag + '_groups_flat'] = np.array(
+        [a for g in groups_r for a in g], np.int64)
+  np.savez_compressed(GOLDEN / 'reset_prune.npz', **out)
+
+
 def make_ica(ref):
   """F8: the ICA natural-gradient update rule (f4 sibling of the dictionary
   update plugins) on sparse codes, one and three iterations, square and
@@ -673,7 +745,7 @@ def make_whitened(ref):
 
 MAKERS = {'fc_c1': make_fc_c1, 'fc_c2_mini': make_fc_c2_mini,
           'subspace': make_subspace, 'conv': make_conv,
-          'trainer': make_trainer, 'trainer_c2': make_trainer_c2,
+          'trainer': make_trainer, 'trainer_c2': make_trainer_c2, 'reset_prune': make_reset_prune,
           'whitened': make_whitened,
           'metrics': make_metrics, 'ica': make_ica}
 

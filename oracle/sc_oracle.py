@@ -689,3 +689,102 @@ def train_steps(batches, dictionary, params, validation_batches=None):
                     'hessian': None if hessian is None else hessian.clone(),
                     'validation': validation})
   return history
+
+
+# --------------------------------------------------------------------------
+# f4: dictionary reset / prune, non-interactive modes
+# --------------------------------------------------------------------------
+def reset_or_prune(dictionary, codes, filter_type, filter_params, action):
+  """vtc/training/sparse_coding.py:522-764 on CPU tensors (cue_user excluded).
+  Randomness as in the reference: numpy's global generator for every choice,
+  torch's CPU generator for the replacement atoms.  Returns (dictionary,
+  affected atoms); pruning edits filter_params['group_assignments'] in place."""
+  groups = filter_params['group_assignments']
+  assert filter_params['coding_mode'] == 'fully-connected'
+
+  def fresh(count, like_rows):
+    target = torch.mean(like_rows.norm(p=2, dim=1))
+    noise = torch.randn((count, dictionary.shape[1]))
+    return noise * (target / noise.norm(p=2, dim=1)[:, None])
+
+  def cosines(rows):
+    nrm = torch.norm(rows, p=2, dim=1, keepdim=True)
+    return (torch.mm(rows, rows.t()) / torch.mm(nrm, nrm.t())).numpy()
+
+  def pick(pairs):
+    out = []
+    for pr in pairs:
+      if pr[0] not in out and pr[1] not in out:
+        out.append(pr[np.random.choice([0, 1])])
+    return out
+
+  def prune(rows):
+    keep = torch.ones(dictionary.shape[0], dtype=torch.bool)
+    keep[torch.as_tensor(np.asarray(rows, dtype=np.int64))] = False
+    if groups is not None:
+      for g in range(len(groups)):
+        groups[g] = [a for a in groups[g] if a not in rows]
+    return dictionary[keep]
+
+  if filter_type == 'random':
+    rows = np.random.choice(np.arange(dictionary.shape[0]),
+                            filter_params['num_to_modify'])
+    if action == 'reset':
+      dictionary[rows] = fresh(len(rows), dictionary)
+      return dictionary, rows
+    return prune(rows), rows
+  if filter_type == 'cosine_sim_threshold':
+    assert not filter_params['cue_user']
+    thr = filter_params['threshold']
+    if filter_params['only_sim_within_group']:
+      hit = []
+      for g in range(len(groups)):
+        members = np.array(groups[g])
+        sims = cosines(dictionary[groups[g]])
+        local = pick(np.argwhere(np.abs(np.triu(sims, k=1)) > thr))
+        if len(local) > 0:
+          if action == 'reset':
+            dictionary[members[local]] = fresh(len(local),
+                                               dictionary[groups[g]])
+          hit.append(members[local])
+      rows = np.array(hit).flatten()
+      if action == 'prune' and len(rows) > 0:
+        return prune(rows), rows
+      return dictionary, rows
+    rows = np.array(pick(np.argwhere(np.triu(cosines(dictionary), k=1) > thr)))
+    if len(rows) > 0:
+      if action == 'reset':
+        dictionary[rows] = fresh(len(rows), dictionary)
+      else:
+        return prune(rows), rows
+    return dictionary, rows
+  if filter_type == 'nonuniformity_within_group':
+    spread = []
+    for g in range(len(groups)):
+      block = codes[:, groups[g]]
+      block = block[torch.sum(block != 0, dim=1) != 0]
+      unit = (block / torch.norm(block, p=2, dim=1, keepdim=True)).numpy()
+      var = []
+      for _ in range(filter_params['num_gc_in_average']):
+        u = np.random.randn(len(groups[g]))
+        u /= np.linalg.norm(u)
+        v = np.random.randn(len(groups[g]))
+        v /= np.linalg.norm(v)
+        basis, _ = np.linalg.qr(np.c_[u, v])
+        pr = np.dot(unit, basis)
+        ang = np.angle(pr[:, 0] + 1j * pr[:, 1])
+        cnt, _ = np.histogram(ang, np.linspace(-np.pi, np.pi, 21))
+        var.append(np.var(cnt / np.sum(cnt)))
+      spread.append(np.mean(var))
+    spread = np.array(spread)
+    odd = np.nonzero(np.logical_and(
+        np.abs(spread - np.mean(spread)) > np.std(spread),
+        np.abs(spread) > 0.002))[0]
+    rows = np.array([groups[x] for x in odd]).flatten()
+    if len(rows) > 0:
+      if action == 'reset':
+        dictionary[rows] = fresh(len(rows), dictionary)
+      else:
+        return prune(rows), rows
+    return dictionary, rows
+  raise KeyError('Unrecognized reset type')

@@ -80,9 +80,6 @@ def test_trainer_rejects_out_of_scope_features_and_bad_names():
           'dictionary_update_algorithm': 'sc_steepest_descent',
           'dict_update_param_schedule': {0: {'stepsize': 0.1,
                                              'num_iters': 1}}}
-  with pytest.raises(NotImplementedError):
-    sparse_coding.train_dictionary(
-        [], [], D, dict(base, dict_element_rp_schedule={0: {}}))
   with pytest.raises(AssertionError):
     sparse_coding.train_dictionary(
         [], [], D, dict(base, inference_param_schedule={1: {}}))

@@ -261,3 +261,26 @@ def test_momentum_schedule():
   t2 = (1 + (1 + 4 * t1 * t1) ** 0.5) / 2
   assert abs(betas[1] - (t1 - 1) / t2) < 1e-15
   assert all(0 <= b < 1 for b in betas)
+
+
+def test_reset_prune_oracle_matches_reference():
+  """f4: every non-interactive reset / prune mode of the reference's
+  reset_or_prune_dict_elements, seeded as in oracle/make_golden.py."""
+  import make_golden
+  g = helpers.load('reset_prune')
+  D0, groups0, C = make_golden.reset_prune_inputs()
+  assert np.array_equal(D0, g['dictionary'])
+  for tag, f_type, f_params, action, np_seed, torch_seed in (
+      make_golden.reset_prune_cases()):
+    groups = [list(x) for x in groups0]
+    params = dict(f_params)
+    params.update({'group_assignments': groups,
+                   'coding_mode': 'fully-connected'})
+    np.random.seed(np_seed)
+    torch.manual_seed(torch_seed)
+    Dn, rows = sc_oracle.reset_or_prune(torch.from_numpy(D0.copy()),
+                                        torch.from_numpy(C), f_type, params,
+                                        action)
+    assert np.array_equal(np.asarray(rows), g[tag + '_affected']), tag
+    assert np.array_equal(Dn.numpy(), g[tag + '_dictionary']), tag
+    assert [len(x) for x in groups] == g[tag + '_group_sizes'].tolist(), tag

@@ -5,11 +5,12 @@ Mirrors the calling convention of vision_transform_codes/training/
 sparse_coding.py (train_dictionary at :9-10, parameter dictionary at :52-117)
 for the part of it that is on the hot path: schedule lookup, code inference,
 Hessian-diagonal EMA, dictionary update (:124-168, :444-517), plus dictionary
-checkpoints (:170-175) and the validation metrics (:177-229, :497-505) as
-device reductions.  TensorBoard image summaries and the interactive reset/prune
-machinery are host-side bookkeeping outside this engine's scope: the former are
-skipped (the metrics are kept in TrainingStep.metrics_log instead of a
-SummaryWriter), the latter raises NotImplementedError if requested.
+checkpoints (:170-175), the parameter dump (:364-379), the validation metrics
+(:177-229, :497-505) as device reductions and the non-interactive modes of the
+dictionary reset / prune schedule (:466-492, :522-764).  TensorBoard image
+summaries are skipped (the metrics are kept in TrainingStep.metrics_log
+instead of a SummaryWriter); asking the reset/prune filter to cue the user for
+a threshold raises NotImplementedError.
 
 Data parallelism (not in the reference): when vtc_hip.parallel is enabled each
 rank feeds its own shard of every batch; inference is local, the dictionary
@@ -124,6 +125,19 @@ class TrainingStep(object):
     # recorded at the iterations of 'training_visualization_schedule'
     self.previous_dictionary = dictionary.clone()
     self.metrics_log = []
+
+  def replace_dictionary(self, dictionary, affected, action):
+    """After reset_or_prune_dict_elements: a pruned dictionary is a new,
+    smaller tensor -- the copy of the previous dictionary and the Hessian
+    diagonal shrink with it (sparse_coding.py:483-491)."""
+    if action == 'prune' and len(affected) > 0:
+      self.dictionary = dictionary
+      self.previous_dictionary = dictionary.clone()
+      if self.uses_hessian:
+        keep = torch.ones(self.hessian_diag.shape[0], dtype=torch.bool)
+        keep[torch.as_tensor(np.asarray(affected, dtype=np.int64))] = False
+        self.hessian_diag = self.hessian_diag[
+            keep.to(self.hessian_diag.device)].contiguous()
 
   def infer_codes(self, batch_images):
     """Keyword call into the inference plugin (sparse_coding.py:124-140)."""
@@ -295,6 +309,38 @@ class TrainingStep(object):
     return metrics
 
 
+def _save_training_params(all_params, logging_path):
+  """training_params.yaml (every parameter but the schedules of when to write
+  files, group assignments as plain lists) and, when the caller passed its own
+  source as 'str_entire_calling_script', called_script.py -- the files the
+  reference leaves next to its logs (sparse_coding.py:364-379)."""
+  import yaml
+  saved = {k: all_params[k] for k in all_params if k not in (
+      'checkpoint_schedule', 'training_visualization_schedule',
+      'group_assignments')}
+  groups = all_params.get('group_assignments')
+  if groups is not None and type(groups[0]) != list:
+    groups = [x.tolist() for x in groups]
+  saved['group_assignments'] = groups
+  with open(logging_path / 'training_params.yaml', 'w') as f:
+    yaml.dump(saved, f, default_flow_style=None)
+  if 'str_entire_calling_script' in all_params:
+    with open(logging_path / 'called_script.py', 'w') as f:
+      f.write(all_params['str_entire_calling_script'])
+
+
+def load_newest_dictionary_checkpoint(checkpoint_dir):
+  """The dictionary of the highest checkpoint iteration in `checkpoint_dir`
+  (the convention of the reference's utils/misc.py:8-20: files named
+  checkpoint_dictionary_iter_<i>, a pickled numpy array each)."""
+  prefix = 'checkpoint_dictionary_iter_'
+  iters = [int(p.name[len(prefix):]) for p in checkpoint_dir.iterdir()
+           if p.is_file() and p.name.startswith(prefix)]
+  print('checkpoint idx: ', max(iters))
+  with open(checkpoint_dir / (prefix + str(max(iters))), 'rb') as f:
+    return pickle.load(f)
+
+
 def train_dictionary(training_image_dataset, validation_image_dataset,
                      init_dictionary, all_params):
   """
@@ -314,10 +360,7 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
   """
   assert 0 in all_params['inference_param_schedule']
   assert 0 in all_params['dict_update_param_schedule']
-  if 'dict_element_rp_schedule' in all_params:
-    raise NotImplementedError(
-        'dict_element_rp_schedule is host-side bookkeeping outside the scope '
-        'of the MI355X engine (SURVEY.md section 8f)')
+  rp_schedule = all_params.get('dict_element_rp_schedule')
   vis_schedule = all_params.get('training_visualization_schedule')
   inf_schedule = all_params['inference_param_schedule']
   upd_schedule = all_params['dict_update_param_schedule']
@@ -330,10 +373,13 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
             'Please ensure the initial dictionary is already normalized')
   ckpt_schedule = all_params.get('checkpoint_schedule')
   logging_path = all_params.get('logging_folder_fullpath')
-  if ckpt_schedule is not None:
+  if ckpt_schedule is not None or (vis_schedule is not None and
+                                   logging_path is not None):
     assert logging_path is not None and type(logging_path) != str, (
         'should be pathlib.Path')
     logging_path.mkdir(parents=True, exist_ok=True)
+    if parallel.rank() == 0:
+      _save_training_params(all_params, logging_path)
   print_interval = all_params.get('stdout_print_interval', 1000)
 
   step = TrainingStep(init_dictionary, all_params)
@@ -353,6 +399,21 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
       if total_iter_idx in upd_schedule:
         step.upd_stepsize = upd_schedule[total_iter_idx]['stepsize']
         step.upd_num_iters = upd_schedule[total_iter_idx]['num_iters']
+      if rp_schedule is not None and total_iter_idx in rp_schedule:
+        # reset or prune dictionary elements (sparse_coding.py:466-492); the
+        # code distribution some filters need comes from the validation set
+        entry = rp_schedule[total_iter_idx]
+        f_params = entry['filter_params']
+        f_params.update({'group_assignments': step.groups,
+                         'coding_mode': step.mode})
+        v_codes = torch.cat([
+            step.infer_codes(v.to(init_dictionary.device))
+            for v in validation_image_dataset])
+        step.replace_dictionary(*reset_or_prune_dict_elements(
+            step.dictionary, v_codes, entry['filter_type'], f_params,
+            entry['action']), action=entry['action'])
+        init_dictionary = step.dictionary
+        previous_dictionary = step.previous_dictionary
       if (ckpt_schedule is not None and total_iter_idx in ckpt_schedule and
           parallel.rank() == 0):
         # plain pickle of the numpy array, the reference's on-disk format
@@ -382,3 +443,182 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
   # whatever is still pending before handing the dictionary back
   vtc_hip.poll_spectrum_checks(block=True)
   return step
+
+
+# ---------------------------------------------------------------------------
+# dictionary reset / prune (sparse_coding.py:466-492, :522-764 of the reference)
+# ---------------------------------------------------------------------------
+def _row_gram(dictionary):
+  """D D^T of the (s, n) dictionary on the device (vtc_gram, exact-f32 MFMA)
+  as a host array; its diagonal holds the squared row norms."""
+  flat = dictionary.reshape(dictionary.shape[0], -1).contiguous()
+  return vtc_hip.gram(flat, transpose_a=False).cpu().numpy()
+
+
+def _cosine_similarities(gram, rows=None):
+  if rows is not None:
+    gram = gram[np.ix_(rows, rows)]
+  norms = np.sqrt(np.diag(gram)).astype(np.float32)
+  return gram / (norms[:, None] * norms[None, :])
+
+
+def _one_of_each_problem_pair(pairs):
+  """Walk the offending (i, j) pairs in row-major order and flag one member
+  (numpy's global generator picks which) of every pair not yet touched."""
+  chosen = []
+  for pair in pairs:
+    if pair[0] not in chosen and pair[1] not in chosen:
+      chosen.append(pair[np.random.choice([0, 1])])
+  return chosen
+
+
+def _noise_rows(count, width, average_norm, device):
+  """Fresh random atoms with the given norm.  Drawn from torch's CPU generator
+  (so that a seeded run is reproducible on any device), then moved."""
+  noise = torch.randn((count, width))
+  noise.mul_(float(average_norm) / noise.norm(p=2, dim=1)[:, None])
+  return noise.to(device)
+
+
+def _write_rows(dictionary, rows, values):
+  """dictionary[rows] = values with the CPU's semantics for repeated indices
+  (numpy's choice() draws with replacement): the last occurrence wins.  An
+  indexed store with duplicates has no defined winner on the device."""
+  rows = np.asarray(rows, dtype=np.int64).ravel()
+  last = {}
+  for position, row in enumerate(rows.tolist()):
+    last[row] = position
+  unique = np.array(sorted(last), dtype=np.int64)
+  source = np.array([last[row] for row in unique.tolist()], dtype=np.int64)
+  dictionary[torch.as_tensor(unique).to(dictionary.device)] = values[
+      torch.as_tensor(source).to(values.device)]
+
+
+def _drop_rows(dictionary, groups, rows):
+  keep = torch.ones(dictionary.shape[0], dtype=torch.bool)
+  keep[torch.as_tensor(np.asarray(rows, dtype=np.int64))] = False
+  if groups is not None:
+    dropped = set(int(x) for x in np.asarray(rows).ravel())
+    for g_idx in range(len(groups)):
+      groups[g_idx] = [a for a in groups[g_idx] if a not in dropped]
+  return dictionary[keep.to(dictionary.device)]
+
+
+def reset_or_prune_dict_elements(dictionary, codes, filter_type,
+                                 filter_params, action):
+  """
+  Reset (to random atoms of average norm) or prune dictionary elements during
+  training -- the non-interactive modes of the reference's function of the
+  same name (training/sparse_coding.py:522-764).
+
+  filter_type: 'random' (filter_params['num_to_modify'] atoms drawn with
+  numpy's global generator), 'cosine_sim_threshold' (one atom of every pair
+  whose cosine similarity exceeds filter_params['threshold']; within groups
+  only -- and on |cos| -- when filter_params['only_sim_within_group']), or
+  'nonuniformity_within_group' (groups whose code phases fill the sphere
+  unevenly, estimated from `codes` over filter_params['num_gc_in_average']
+  random great circles).  filter_params also carries 'coding_mode' and
+  'group_assignments' (pruning edits the group lists in place, as the
+  reference does).  action: 'reset' or 'prune'.
+
+  Returns (dictionary, affected_atoms): the same tensor, modified in place,
+  for 'reset'; a new, smaller tensor for 'prune'.  The similarity matrix is a
+  device contraction (vtc_gram); the selection logic runs on the host like the
+  reference's (it goes through .cpu().numpy() there as well).
+  """
+  groups = filter_params['group_assignments']
+  coding_mode = filter_params['coding_mode']
+  if coding_mode == 'convolutional':
+    raise NotImplementedError('Not yet implemented for convolutional dict')
+  if coding_mode != 'fully-connected':
+    raise KeyError('Unrecognized coding mode')
+  assert action in ('reset', 'prune')
+  width, device = dictionary.shape[1], dictionary.device
+
+  def average_norm(gram, rows=None):
+    diag = np.diag(gram) if rows is None else np.diag(gram)[rows]
+    return np.mean(np.sqrt(diag).astype(np.float32))
+
+  if filter_type == 'random':
+    modify_these = np.random.choice(np.arange(dictionary.shape[0]),
+                                    filter_params['num_to_modify'])
+    if action == 'reset':
+      gram = _row_gram(dictionary)
+      _write_rows(dictionary, modify_these, _noise_rows(
+          len(modify_these), width, average_norm(gram), device))
+    else:
+      dictionary = _drop_rows(dictionary, groups, modify_these)
+    return dictionary, modify_these
+
+  if filter_type == 'cosine_sim_threshold':
+    if filter_params['cue_user']:
+      raise NotImplementedError(
+          'interactive threshold selection (a matplotlib window and input()) '
+          'is not part of this engine: pass filter_params["threshold"]')
+    threshold = filter_params['threshold']
+    gram = _row_gram(dictionary)
+    if filter_params['only_sim_within_group']:
+      assert groups is not None
+      flagged = []
+      for g_idx in range(len(groups)):
+        members = np.array(groups[g_idx])
+        sims = _cosine_similarities(gram, members)
+        pairs = np.argwhere(np.abs(np.triu(sims, k=1)) > threshold)
+        local = _one_of_each_problem_pair(pairs)
+        if len(local) > 0:
+          print('Action ', action, 'applied to ', local, 'in group', g_idx)
+          if action == 'reset':
+            _write_rows(dictionary, members[local], _noise_rows(
+                len(local), width, average_norm(gram, members), device))
+          flagged.append(members[local])
+      modify_these = np.array(flagged).flatten()
+      if action == 'prune' and len(modify_these) > 0:
+        dictionary = _drop_rows(dictionary, groups, modify_these)
+      return dictionary, modify_these
+    sims = _cosine_similarities(gram)
+    pairs = np.argwhere(np.triu(sims, k=1) > threshold)
+    modify_these = np.array(_one_of_each_problem_pair(pairs))
+    if len(modify_these) > 0:
+      if action == 'reset':
+        _write_rows(dictionary, modify_these, _noise_rows(
+            len(modify_these), width, average_norm(gram), device))
+      else:
+        dictionary = _drop_rows(dictionary, groups, modify_these)
+    return dictionary, modify_these
+
+  if filter_type == 'nonuniformity_within_group':
+    num_great_circles = filter_params['num_gc_in_average']
+    host_codes = codes.cpu().numpy()
+    spread = []
+    for g_idx in range(len(groups)):
+      members = np.array(groups[g_idx])
+      block = host_codes[:, members]
+      block = block[np.sum(block != 0, axis=1) != 0]
+      renormed = block / np.linalg.norm(block, axis=1, keepdims=True)
+      variances = []
+      for _ in range(num_great_circles):
+        first = np.random.randn(len(members))
+        first /= np.linalg.norm(first)
+        second = np.random.randn(len(members))
+        second /= np.linalg.norm(second)
+        plane, _ = np.linalg.qr(np.c_[first, second])
+        proj = np.dot(renormed, plane)
+        angle = np.angle(proj[:, 0] + 1j * proj[:, 1])
+        counts, _ = np.histogram(angle, np.linspace(-np.pi, np.pi, 21))
+        variances.append(np.var(counts / np.sum(counts)))
+      spread.append(np.mean(variances))
+    spread = np.array(spread)
+    outliers = np.nonzero(np.logical_and(
+        np.abs(spread - np.mean(spread)) > np.std(spread),
+        np.abs(spread) > 0.002))[0]
+    modify_these = np.array([groups[x] for x in outliers]).flatten()
+    if len(modify_these) > 0:
+      if action == 'reset':
+        gram = _row_gram(dictionary)
+        _write_rows(dictionary, modify_these, _noise_rows(
+            len(modify_these), width, average_norm(gram), device))
+      else:
+        dictionary = _drop_rows(dictionary, groups, modify_these)
+    return dictionary, modify_these
+
+  raise KeyError('Unrecognized reset type')
