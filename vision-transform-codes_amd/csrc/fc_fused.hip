@@ -488,6 +488,22 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   // loads/stores of C and the bf16 publication of Y' happen at group edges.
   auto epilogue_elem = [&](int p, int e, const f32x16v& Gp, float beta) {
     const int g = e >> 2, k = e & 3;
+    if (MODE == 7) {         // diagnostic: step 1 with (almost) no epilogue work
+      const float cn = Y[p][e] + Gp[e];
+      Y[p][e] = cn;
+      cn4[k] = cn;
+      if (k == 3) {
+        if (p < CREG) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Cr[p < CREG ? p : 0][4 * g + q] = cn4[q];
+        } else {
+          *reinterpret_cast<float4*>(Cst + cst_ln + (p - CREG) * 16384 +
+                                     g * 1024) =
+              make_float4(cn4[0], cn4[1], cn4[2], cn4[3]);
+        }
+      }
+      return;
+    }
     if (k == 0) {
       if (p < CREG) {
         cold4 = make_float4(Cr[p < CREG ? p : 0][4 * g + 0],
@@ -675,7 +691,9 @@ static int launch_fused(const FusedParams& P, hipStream_t st) {
 template <int NPH, int NP, bool F16>
 static int launch_stamped(FusedParams P, hipStream_t st) {
   using L = FusedLds<NPH, NP>;
-  auto kernel = fused_fista_kernel<NPH, NP, VTC_SOFT, F16, true>;
+  static const bool no_epilogue = getenv("VTC_FUSED_NOEPI") != nullptr;
+  auto kernel = no_epilogue ? fused_fista_kernel<NPH, NP, 7, F16, true>
+                            : fused_fista_kernel<NPH, NP, VTC_SOFT, F16, true>;
   unsigned long long* dev = nullptr;
   VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
   VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
