@@ -1,0 +1,39 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence of a round on the MI355X box into gpurun_out/$1/.
+#   bash tools/profile_round.sh r02
+set -o pipefail
+tag=${1:-r02}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+echo "== bench" && timeout -k 10 400 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -c 600 $out/bench_default.json
+echo "== kernel stats of the bench step"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_stats -o b -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_stats.log 2>&1
+cp $out/bench_stats/b_kernel_stats.csv $out/bench_kernel_stats.csv 2>/dev/null
+run_pmc() {  # name, counters..., then -- command
+  name=$1; shift
+  ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $out/pmc_$name -o p -- "$@" > $out/pmc_$name.log 2>&1
+}
+echo "== PMC passes, fused FC kernel f16x3"
+run_pmc fc1 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 tools/run_inference.py --precision f16x3 --reps 2
+run_pmc fc2 FETCH_SIZE -- python3 tools/run_inference.py --precision f16x3 --reps 2
+run_pmc fc3 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 tools/run_inference.py --precision f16x3 --reps 2
+run_pmc fc4 SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -- python3 tools/run_inference.py --precision f16x3 --reps 2
+python3 tools/pmc_summary.py $out fused_fista_kernel > $out/fused_f16x3_pmc.txt; cat $out/fused_f16x3_pmc.txt
+echo "== secondary configs"
+timeout -k 10 300 python3 tools/run_configs.py > $out/secondary_configs.txt 2>&1; grep -v amdgpu $out/secondary_configs.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cfg_stats -o c -- python3 tools/run_configs.py > /dev/null 2>&1
+cp $out/cfg_stats/c_kernel_stats.csv $out/secondary_kernel_stats.csv 2>/dev/null
+echo "== PMC passes, streamed kernel (subspace configs[3], 50 iterations)"
+run_pmc st1 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 tools/run_subspace_once.py
+run_pmc st2 FETCH_SIZE -- python3 tools/run_subspace_once.py
+run_pmc st3 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 tools/run_subspace_once.py
+python3 tools/pmc_summary.py $out fused_stream_kernel > $out/stream_pmc.txt; cat $out/stream_pmc.txt
+echo "== example sizes"
+timeout -k 10 200 python3 tools/time_fc_example.py 2>&1 | grep -v amdgpu > $out/example_sizes.txt
+timeout -k 10 200 python3 tools/time_conv_example.py 2>&1 | grep -v amdgpu >> $out/example_sizes.txt; cat $out/example_sizes.txt
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ex_stats -o e -- python3 tools/time_fc_example.py > /dev/null 2>&1
+cp $out/ex_stats/e_kernel_stats.csv $out/fc_example_kernel_stats.csv 2>/dev/null
+rm -rf $out/bench_stats $out/cfg_stats $out/ex_stats
+echo done
