@@ -68,8 +68,12 @@ def run(images_padded, dictionary, kernel_stride, padding_dims,
   name = precision if precision is not None else (
       vtc_hip.get_default_precision())
   if name == 'auto':
-    name = 'bf16x3' if (geom.s >= 32 and lib.vtc_conv_x3_supported(
-        ctypes.byref(geom))) else 'f32'
+    # hard thresholds stay on the exact-f32 kernels: a discontinuous threshold
+    # turns the bf16x3 products' ~1e-5 differences into flips of the cutoff's
+    # size, which the split path is only pinned for over a single iteration
+    name = 'bf16x3' if (geom.s >= 32 and not hard_threshold and
+                        lib.vtc_conv_x3_supported(ctypes.byref(geom))) else (
+                            'f32')
   if name == 'bf16':
     raise NotImplementedError('convolutional inference has no bf16 fast mode')
   vtc_hip.check(lib.vtc_conv_ista_fista(

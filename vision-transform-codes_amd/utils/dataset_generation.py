@@ -15,17 +15,22 @@ import vtc_hip
 
 def draw_patch_positions(num_samples, image_shape, patch_dimensions,
                          edge_buffer, num_images, rng=np.random):
-  """The three randint calls per patch of dataset_generation.py:205-210, for
-  equally sized images.  Returns int32 arrays (img_idx, vert_pos, horz_pos)."""
-  max_vert = image_shape[0] - patch_dimensions[0] - edge_buffer
-  max_horz = image_shape[1] - patch_dimensions[1] - edge_buffer
+  """The three randint calls per patch of dataset_generation.py:205-214.
+  image_shape: one (h, w) for equally sized images, or a sequence of
+  num_images shapes -- the reference keeps per-image position ranges
+  (:185-198).  Returns int32 arrays (img_idx, vert_pos, horz_pos)."""
+  shapes = [tuple(image_shape)[:2]] * num_images if np.isscalar(
+      image_shape[0]) else [tuple(x)[:2] for x in image_shape]
+  assert len(shapes) == num_images
+  max_vert = [x[0] - patch_dimensions[0] - edge_buffer for x in shapes]
+  max_horz = [x[1] - patch_dimensions[1] - edge_buffer for x in shapes]
   img_idx = np.empty(num_samples, np.int32)
   vert = np.empty(num_samples, np.int32)
   horz = np.empty(num_samples, np.int32)
   for p_idx in range(num_samples):
     img_idx[p_idx] = rng.randint(low=0, high=num_images)
-    vert[p_idx] = rng.randint(low=edge_buffer, high=max_vert)
-    horz[p_idx] = rng.randint(low=edge_buffer, high=max_horz)
+    vert[p_idx] = rng.randint(low=edge_buffer, high=max_vert[img_idx[p_idx]])
+    horz[p_idx] = rng.randint(low=edge_buffer, high=max_horz[img_idx[p_idx]])
   return img_idx, vert, horz
 
 
