@@ -101,6 +101,13 @@ int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
 size_t vtc_lambda_max_workspace_bytes(int64_t n);
 int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* Same; the kernel also stores the two floats through host_mirror (may be
+ * NULL), a device-visible HOST pointer (pinned memory): a caller that keeps
+ * eta on the device can still notice a failed eigen-solve -- the reference's
+ * symeig raises there, ista_fista.py:75-79 -- without a copy or a wait. */
+int vtc_lambda_max_mirrored(const float* symmetric, int64_t n, float* out,
+                            float* host_mirror, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ---- fully-connected inference (row a1) ------------------------------- */
 size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n, int64_t s,

@@ -811,17 +811,15 @@ int run_fused(const float* images, const float* dictionary,
                        dictionary, (int64_t)s * kFN, dscale);
     VTC_LAUNCH_CHECK();
   }
-  for (int part = 0; part < parts; ++part) {
-    if (f16)
-      hipLaunchKernelGGL(pack_dictionary_kernel<true>, dim3(256), dim3(256), 0,
-                         st, dictionary, (int)s, packs[2 * part],
-                         packs[2 * part + 1], part, dscale);
-    else
-      hipLaunchKernelGGL(pack_dictionary_kernel<false>, dim3(256), dim3(256),
-                         0, st, dictionary, (int)s, packs[2 * part],
-                         packs[2 * part + 1], part, dscale);
-    VTC_LAUNCH_CHECK();
-  }
+  if (f16)
+    hipLaunchKernelGGL(pack_dictionary_kernel<true>, dim3(256), dim3(256), 0,
+                       st, dictionary, (int)s, packs[0], packs[1], packs[2],
+                       packs[3], dscale);
+  else
+    hipLaunchKernelGGL(pack_dictionary_kernel<false>, dim3(256), dim3(256), 0,
+                       st, dictionary, (int)s, packs[0], packs[1], packs[2],
+                       packs[3], dscale);
+  VTC_LAUNCH_CHECK();
   P.images = images;
   P.init = initial_codes;
   P.codes = codes;

@@ -72,11 +72,13 @@ static __global__ __launch_bounds__(1024) void dictionary_scale_kernel(
   }
 }
 
+// Both parts in one pass (loA / loT null: hi part only).
 template <bool F16>
 __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
                                        unsigned short* __restrict__ packA,
                                        unsigned short* __restrict__ packT,
-                                       int lo,
+                                       unsigned short* __restrict__ loA,
+                                       unsigned short* __restrict__ loT,
                                        const float* __restrict__ scale) {
   const float sg = F16 ? scale[0] : 1.f;
   const int64_t frags = (int64_t)s * kFN / 8;  // 16-byte units per packing
@@ -89,8 +91,11 @@ __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
       const int t = (int)(f >> 4), ks = (int)(f & 15);
       const float* src = D + (int64_t)(32 * t + r) * kFN + 16 * ks + 8 * h;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        packA[u * 8 + j] = split_part<F16>(src[j] * sg, lo);
+      for (int j = 0; j < 8; ++j) {
+        const float v = src[j] * sg;
+        packA[u * 8 + j] = split_part<F16>(v, 0);
+        if (loA) loA[u * 8 + j] = split_part<F16>(v, 1);
+      }
     }
     {
       const int64_t f = u >> 6;  // = (p*8 + nb)*8 + ks
@@ -98,8 +103,11 @@ __global__ void pack_dictionary_kernel(const float* __restrict__ D, int s,
       const float* src =
           D + (int64_t)(128 * p + 16 * ks + 8 * h) * kFN + 32 * nb + r;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        packT[u * 8 + j] = split_part<F16>(src[(int64_t)j * kFN] * sg, lo);
+      for (int j = 0; j < 8; ++j) {
+        const float v = src[(int64_t)j * kFN] * sg;
+        packT[u * 8 + j] = split_part<F16>(v, 0);
+        if (loT) loT[u * 8 + j] = split_part<F16>(v, 1);
+      }
     }
   }
 }

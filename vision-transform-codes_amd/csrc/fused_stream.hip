@@ -844,15 +844,17 @@ int run_stream(const float* images, const float* dictionary,
                        dictionary, (int64_t)slots * kFN, dscale);
     VTC_LAUNCH_CHECK();
   }
-  for (int part = 0; part < 2; ++part) {
-    unsigned short* pa = packs[part];
-    unsigned short* pt = packs[part] + (size_t)slots * kFN;
+  {
+    unsigned short* hiT = packs[0] + (size_t)slots * kFN;
+    unsigned short* loT = packs[1] + (size_t)slots * kFN;
     if (f16)
       hipLaunchKernelGGL(pack_dictionary_kernel<true>, dim3(1024), dim3(256),
-                         0, st, dictionary, (int)slots, pa, pt, part, dscale);
+                         0, st, dictionary, (int)slots, packs[0], hiT,
+                         packs[1], loT, dscale);
     else
       hipLaunchKernelGGL(pack_dictionary_kernel<false>, dim3(1024), dim3(256),
-                         0, st, dictionary, (int)slots, pa, pt, part, dscale);
+                         0, st, dictionary, (int)slots, packs[0], hiT,
+                         packs[1], loT, dscale);
     VTC_LAUNCH_CHECK();
   }
   const int nph = (int)(slots / kPhaseAtoms);

@@ -256,6 +256,63 @@ static inline int gemm_vec_ok(const float* p, int64_t ld) {
 }
 
 // k_slices > 1 => split-K, the epilogue receives the slice index.
+// Small problems (a handful of 128x128 tiles: the Gram matrix and the residual
+// of the reference's example sizes, 256 atoms x 250 patches) run latency-bound
+// on the kernel above -- 4 blocks, each walking all of K behind its LDS staging.
+// Here a block owns ONE 32x32 output tile, its four waves split K four ways,
+// operands go from L2 straight into the MFMA operand registers (one float per
+// lane and product), and the four partial tiles are summed through LDS in wave
+// order (bitwise reproducible).  Element-wise epilogues only.
+template <bool A_KC, bool B_KC, class Epi>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
+                                                             Epi epi) {
+  __shared__ float part[3][16][64];
+  resolve_epilogue(epi, 0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tiles_n = (g.N + 31) / 32;
+  const int64_t m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+  const int64_t row = m0 + (lane & 31), col = n0 + (lane & 31);
+  const int kk = lane >> 5;
+  // this wave's K range, a multiple of 16 long
+  const int64_t quarter = ((g.K + 63) / 64) * 16;
+  const int64_t k_begin = wave * quarter;
+  const int64_t k_end = k_begin + quarter < g.K ? k_begin + quarter : g.K;
+  const bool row_ok = row < g.M, col_ok = col < g.N;
+  const float* pa = g.A + (A_KC ? row * g.lda : row);
+  const float* pb = g.B + (B_KC ? col * g.ldb : col);
+  const int64_t sa = A_KC ? 1 : g.lda, sb = B_KC ? 1 : g.ldb;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int64_t k0 = k_begin; k0 < k_end; k0 += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = k0 + 2 * j + kk;
+      a[j] = (row_ok && k < k_end) ? pa[k * sa] : 0.f;
+      b[j] = (col_ok && k < k_end) ? pb[k * sb] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (acc[r] + part[0][r][lane]) +
+                      (part[1][r][lane] + part[2][r][lane]);
+      const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (orow < g.M && col < g.N) epi(orow, col, v, 0);
+    }
+  }
+  epi.block_end();
+}
+
 template <bool A_KC, bool B_KC, class Epi>
 static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
                            int64_t ldb, int64_t M, int64_t N, int64_t K,
@@ -284,6 +341,15 @@ static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
   g.a_batch = a_batch;
   g.b_batch = b_batch;
   const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
+  if constexpr (!epi_whole_tile<Epi>::value) {
+    if (tiles <= 8 && k_slices == 1 && batches == 1) {
+      const int64_t small_tiles = ceil_div(M, 32) * ceil_div(N, 32);
+      hipLaunchKernelGGL((gemm_f32_small_kernel<A_KC, B_KC, Epi>),
+                         dim3((unsigned)small_tiles), dim3(256), 0, st, g, epi);
+      VTC_LAUNCH_CHECK();
+      return VTC_OK;
+    }
+  }
   if (tiles > 0x7fffffffLL) {
     set_error("gemm: too many tiles (%lld)", (long long)tiles);
     return VTC_ERR_INVALID_ARGUMENT;

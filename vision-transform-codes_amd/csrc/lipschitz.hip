@@ -200,7 +200,8 @@ constexpr int kLzThreads = 512;
 
 template <bool STAMP>
 __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
-    const float* __restrict__ G, int n, int k, float* __restrict__ out) {
+    const float* __restrict__ G, int n, int k, float* __restrict__ out,
+    float* __restrict__ mirror) {
   __shared__ __attribute__((aligned(16))) float vcur[256];  // b_{j-1} v_j
   __shared__ __attribute__((aligned(16))) float partial[4][256];
   __shared__ double red_a[8], red_b[4];
@@ -343,6 +344,10 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   if (tid == 0) {
     out[0] = lf;
     out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+    if (mirror) {       // host-visible copy for the caller's error channel
+      mirror[0] = lf;
+      mirror[1] = 1.f / lf;
+    }
     if (STAMP)
       for (int q = 0; q < 4; ++q) out[2 + q] = (float)st_acc[q];
   }
@@ -367,7 +372,7 @@ __device__ __forceinline__ double block_sum_all(double v, double* red) {
 
 __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
     const float* __restrict__ G, int n, int k, float* __restrict__ V,
-    float* __restrict__ out) {
+    float* __restrict__ out, float* __restrict__ mirror) {
   __shared__ float vcur[kLanczosLargeN];
   __shared__ float wl[kLanczosLargeN];
   __shared__ float coef[kLanczosMaxK];
@@ -476,6 +481,10 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
     if (t == 0) {
       out[0] = lf;
       out[1] = 1.f / lf;
+      if (mirror) {
+        mirror[0] = lf;
+        mirror[1] = 1.f / lf;
+      }
     }
   }
 }
@@ -490,9 +499,9 @@ extern "C" size_t vtc_lambda_max_workspace_bytes(int64_t n) {
 }
 
 // out: 2 floats on the device: [lambda_max, 1/lambda_max]
-extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
-                              void* workspace, size_t workspace_bytes,
-                              void* stream) {
+static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
+                           float* mirror, void* workspace,
+                           size_t workspace_bytes, void* stream) {
   VTC_REQUIRE(symmetric && out, "vtc_lambda_max: null pointer");
   VTC_REQUIRE(n > 0, "vtc_lambda_max: bad size");
   if (n > kLanczosLargeN) {
@@ -508,7 +517,7 @@ extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
     }
     hipLaunchKernelGGL(lanczos_large_kernel, dim3(1), dim3(kLanczosThreads), 0,
                        as_stream(stream), symmetric, (int)n, k,
-                       static_cast<float*>(workspace), out);
+                       static_cast<float*>(workspace), out, mirror);
     VTC_LAUNCH_CHECK();
     return VTC_OK;
   }
@@ -524,11 +533,26 @@ extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
   if (stamps)
     hipLaunchKernelGGL(lanczos_lambda_max_kernel<true>, dim3(1),
                        dim3(kLzThreads), 0, as_stream(stream), symmetric,
-                       (int)n, k_small, out);
+                       (int)n, k_small, out, mirror);
   else
     hipLaunchKernelGGL(lanczos_lambda_max_kernel<false>, dim3(1),
                        dim3(kLzThreads), 0, as_stream(stream), symmetric,
-                       (int)n, k_small, out);
+                       (int)n, k_small, out, mirror);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
+}
+
+extern "C" int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
+                              void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  return lambda_max_impl(symmetric, n, out, nullptr, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int vtc_lambda_max_mirrored(const float* symmetric, int64_t n,
+                                       float* out, float* host_mirror,
+                                       void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return lambda_max_impl(symmetric, n, out, host_mirror, workspace,
+                         workspace_bytes, stream);
 }

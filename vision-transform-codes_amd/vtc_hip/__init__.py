@@ -60,6 +60,7 @@ SIGNATURES = {
     'vtc_gram': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'vtc_lambda_max_workspace_bytes': (_sz, [_i64]),
     'vtc_lambda_max': (_i32, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    'vtc_lambda_max_mirrored': (_i32, [_vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     'vtc_fc_ista_fista_workspace_bytes': (_sz, [_i64, _i64, _i64, _i32]),
     'vtc_fc_ista_fista': (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
                                  _f32, _i32, _i32, _i32, _f32, _i32, _vp, _sz,
@@ -264,12 +265,12 @@ def gram(matrix, transpose_a):
 
 LANCZOS_MAX_N = 1024
 _use_device_eigensolver = os.environ.get('VTC_EIGEN', 'lanczos') != 'library'
-# Deferred error channel of the sync-free path: [lambda_max, eta] of every
-# device-side eigen-solve is copied (8 bytes, asynchronously) to pinned host
-# memory and looked at once its event has completed -- at the next plugin
-# call, never by waiting.  A non-finite spectrum then raises the reference's
-# RuntimeError (ista_fista.py:75-79) one call late instead of stalling every
-# step behind a device-to-host read.  Set to False to drop the copy as well.
+# Deferred error channel of the sync-free path: the eigen-solve kernel also
+# stores [lambda_max, eta] through a pointer into pinned host memory (no copy,
+# no wait), which is looked at once the event recorded behind the kernel has
+# completed -- at the next plugin call.  A non-finite spectrum then raises the
+# reference's RuntimeError (ista_fista.py:75-79) one call late instead of
+# stalling every step behind a device-to-host read.  False: no mirror at all.
 spectrum_check = os.environ.get('VTC_SPECTRUM_CHECK', '1') != '0'
 _pending_spectra = []
 
@@ -299,16 +300,19 @@ def poll_spectrum_checks(block=False):
       _report_bad_spectrum(dictionary)
 
 
-def lambda_max_device(gram_matrix):
+def lambda_max_device(gram_matrix, host_mirror=None):
   """[lambda_max, 1 / lambda_max] of a symmetric (n, n) device matrix,
   n <= 1024, as a 2-element device tensor (vtc_lambda_max: one small HIP
-  kernel, Lanczos + Sturm counts).  Nothing comes back to the host."""
+  kernel, Lanczos + Sturm counts).  host_mirror: optional pinned CPU tensor of
+  2 floats the kernel writes the same values through."""
   lib = load_library()
   n = gram_matrix.shape[0]
   out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
   ws = workspace(lib.vtc_lambda_max_workspace_bytes(n), gram_matrix.device)
-  check(lib.vtc_lambda_max(ptr(gram_matrix), n, ptr(out), ptr(ws),
-                           ws.numel(), current_stream(gram_matrix.device)),
+  check(lib.vtc_lambda_max_mirrored(
+      ptr(gram_matrix), n, ptr(out),
+      ctypes.c_void_p(host_mirror.data_ptr() if host_mirror is not None else 0),
+      ptr(ws), ws.numel(), current_stream(gram_matrix.device)),
         'vtc_lambda_max')
   return out
 
@@ -322,10 +326,11 @@ def stepsize_on_device(gram_matrix, dictionary_for_message):
   reference keeps it (ista_fista.py:80): no host synchronisation.  Failure
   of the eigen-solve surfaces through poll_spectrum_checks()."""
   poll_spectrum_checks()
-  out = lambda_max_device(gram_matrix)
+  pinned = None
   if spectrum_check:
     pinned = torch.empty(2, dtype=torch.float32, pin_memory=True)
-    pinned.copy_(out, non_blocking=True)
+  out = lambda_max_device(gram_matrix, pinned)
+  if spectrum_check:
     event = torch.cuda.Event()
     event.record(torch.cuda.current_stream(gram_matrix.device))
     _pending_spectra.append((event, pinned, dictionary_for_message))
