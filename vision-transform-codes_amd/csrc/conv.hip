@@ -25,6 +25,8 @@
 //   analysis   g[b,s,p,q]      = sum_{c,dy,dx} r[b,c,p*sv+dy,q*sh+dx] D[s,c,dy,dx]
 //   gradient   dD[s,c,dy,dx]   = sum_{b,p,q} codes[b,s,p,q] r[b,c,p*sv+dy,q*sh+dx]
 #include "common.h"
+
+#include <stdlib.h>
 #include "gemm_f32.h"
 #include "fc_fused.h"
 
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(1024) void conv_apply_kernel(
 
 static size_t conv_x3_image_bytes(const ConvGeo& g) {
   CxPlan p;
-  return cx_plan(g, &p) ? cx_image_bytes(p) : 0;
+  return cx_plan(g, &p) ? cx_image_bytes(p) + cx_fused_bytes(p) : 0;
 }
 
 static size_t conv_inference_ws(const ConvGeo& g) {
@@ -543,10 +545,23 @@ extern "C" int vtc_conv_ista_fista(
   float* Kt = ws.take<float>((size_t)g.s * ctaps);
   uint16_t* syn_image = nullptr;
   uint16_t* ana_image = nullptr;
+  uint16_t* synp_image = nullptr;   // fused iteration kernel (conv_x3.h)
+  float* partial = nullptr;
   if (x3) {
     syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
     rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
+    // fused iteration kernel: FISTA, soft threshold, no early stopping
+    static const bool no_fused = getenv("VTC_CONV_NO_FUSED") != nullptr;
+    if (rc == VTC_OK && xp.fused_lds != 0 && variant == VTC_FISTA &&
+        threshold == VTC_SOFT && early_stopping_epsilon < 0.f && !no_fused) {
+      synp_image = ws.take<uint16_t>(xp.synp_image_bytes / 2);
+      partial = ws.take<float>(xp.partial_bytes / sizeof(float));
+      hipLaunchKernelGGL(conv_x3_pack_synp_kernel, dim3(256), dim3(256), 0, st,
+                         dictionary, synp_image, g.s, xp.k, xp.slots,
+                         xp.chunks);
+      VTC_LAUNCH_CHECK();
+    }
     if (rc != VTC_OK) return rc;
   }
   const bool patch_path = !x3 && patch_geometry(g);
@@ -597,7 +612,19 @@ extern "C" int vtc_conv_ista_fista(
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
     ProxParams pp{eta, cutoff, fista ? betas[k] : 0.f, threshold,
                   fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr};
-    if (x3) {
+    if (x3 && synp_image) {
+      // synthesis fused into the analysis epilogue: the residual of the first
+      // iteration from the stand-alone synthesis, the later ones from the
+      // partial tiles of the previous fused launch
+      if (k == 0) {
+        rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
+        if (rc != VTC_OK) return rc;
+      }
+      rc = cx_launch_fused(residual, ana_image, synp_image, Y, codes, partial,
+                           images_padded, residual, g, xp, pp,
+                           k + 1 < num_iters, st);
+      if (rc != VTC_OK) return rc;
+    } else if (x3) {
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
       if (rc != VTC_OK) return rc;
       rc = cx_launch_analysis(residual, ana_image, Y, codes, g, xp, pp, st);

@@ -538,6 +538,380 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   }
 }
 
+// ------------------------------------------------ fused iteration kernel
+// One conv-FISTA iteration moves the code maps (36 MB per 256x256 image at
+// 128 kernels) five times when synthesis and analysis are separate launches:
+// the analysis reads Y and the codes and writes both, the synthesis reads the
+// new Y once more -- with a 1.6x halo overlap.  Here the synthesis rides on the
+// analysis epilogue: the new Y tile is still in the accumulator layout (lane =
+// code column, register = atom), which -- with the atoms of a 16-atom k-step
+// taken in the order (j & 3) + 8 (j >> 2) + 4 half, baked into the packed
+// synthesis operand -- IS the B-operand layout of Q[tap, pos] = sum_s D[s, tap]
+// Y'[s, pos].  Each wave (one code row of the block's band of 8) forms Q for
+// its 64 code columns and its chunk of 64 atoms and folds it (col2im, as in
+// conv_synth_x3_kernel) into its private 11 x 74 window in LDS; the block adds
+// the 8 windows in wave order and writes ONE partial reconstruction tile
+// (18 x 74) to its own slot of a small buffer.  conv_partial_reduce_kernel
+// then sums, for every pixel, the <= 12 partial tiles that cover it in a fixed
+// order and forms the next residual.  Per iteration the code maps are read
+// twice and written twice, nothing else of that size moves.
+// FISTA, soft threshold, no early stopping (the configuration of every
+// training run); other options take the two-kernel path.
+template <int K>
+struct CxFused {
+  static constexpr int ROWS = 8;                    // code rows per block
+  static constexpr int AC = 64;                     // atoms per chunk
+  static constexpr int WP = kCxStrip + K;           // window pitch (floats)
+  static constexpr int TH = ROWS + K - 1;           // partial tile rows
+  static constexpr int TW = kCxStrip + K - 1;       // partial tile columns
+  static constexpr int SYN_PITCH = AC + 8;          // elements per slot row
+  static constexpr size_t ana_bytes = (size_t)2 * K * AC * 16 * 2;
+  static constexpr size_t syn_bytes =
+      (size_t)2 * CxDims<K>::SLOTS * SYN_PITCH * 2;
+  static constexpr size_t win_bytes = (size_t)2 * TH * kCxAnaPitch * 2;
+  static constexpr size_t priv_bytes = (size_t)8 * K * WP * 4;
+  static constexpr size_t lds = ana_bytes + syn_bytes + win_bytes + priv_bytes;
+};
+
+// synp image (uint16): [chunk][plane][slot][AC + 8]: element a of a slot row
+// holds D[chunk*64 + 32 (a>>5) + 16 ((a>>4)&1) + 4 ((a>>3)&1) + (a&3) +
+// 8 ((a>>2)&1)][tap(slot)] -- the k order of the accumulator layout.
+__global__ void conv_x3_pack_synp_kernel(const float* __restrict__ D,
+                                         uint16_t* __restrict__ synp, int s,
+                                         int k, int slots, int chunks) {
+  const int taps = k * k;
+  const int pitch = 64 + 8;
+  const int64_t plane = (int64_t)slots * pitch;
+  const int64_t total = (int64_t)chunks * plane;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int chunk = (int)(e / plane);
+    const int rem = (int)(e % plane);
+    const int slot = rem / pitch, a = rem % pitch;
+    float v = 0.f;
+    const int t = cx_slot_tap(slot, k);
+    if (a < 64 && t >= 0) {
+      const int j = a & 7;
+      const int atom = chunk * 64 + 32 * (a >> 5) + 16 * ((a >> 4) & 1) +
+                       4 * ((a >> 3) & 1) + (j & 3) + 8 * (j >> 2);
+      if (atom < s) v = D[(int64_t)atom * taps + t];
+    }
+    const __bf16 h = (__bf16)v;
+    uint16_t* hi = synp + (int64_t)chunk * 2 * plane + rem;
+    hi[0] = cx_bits(h);
+    hi[plane] = cx_bits((__bf16)(v - (float)h));
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(512) void conv_fused_x3_kernel(
+    const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
+    const uint16_t* __restrict__ synp_image, float* __restrict__ Y,
+    float* __restrict__ C, float* __restrict__ partial, ConvGeo g, int tiles_v,
+    int tiles_u, int chunks, ProxParams pp, int do_synth,
+    unsigned long long* stamps) {
+  using Dm = CxDims<K>;
+  using F = CxFused<K>;
+  constexpr int AC = F::AC, MT = Dm::MT, WP = F::WP;
+  unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int slot_) {
+    if (!stamps) return;
+    unsigned long long now;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+    st_acc[slot_] += now - st_prev;
+    st_prev = now;
+  };
+  if (stamps)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+  extern __shared__ __attribute__((aligned(16))) char cx_lds[];
+  const int plane = K * AC * 16;                    // analysis plane, elements
+  uint16_t* Dh = reinterpret_cast<uint16_t*>(cx_lds);
+  uint16_t* Dl = Dh + plane;
+  const int splane = Dm::SLOTS * F::SYN_PITCH;      // synthesis plane
+  uint16_t* Sh = Dl + plane;
+  uint16_t* Sl = Sh + splane;
+  uint16_t* Rh = Sl + splane;
+  uint16_t* Rl = Rh + F::TH * kCxAnaPitch;
+  float* priv = reinterpret_cast<float*>(Rl + F::TH * kCxAnaPitch);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;       // wave = code row of the band
+  const int l31 = lane & 31, half = lane >> 5;
+  // block -> (band, strip), XCD aware as in conv_analysis_x3_kernel
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile_v = slot % tiles_v;
+  const int64_t band = (int64_t)(slot / tiles_v) * 8 + xcd;
+  if (band >= (int64_t)tiles_u * chunks * g.b) return;   // whole block
+  const int chunk = (int)(band % chunks);
+  const int tile_u = (int)((band / chunks) % tiles_u);
+  const int64_t img = band / ((int64_t)chunks * tiles_u);
+  const int u0 = tile_u * F::ROWS, v0 = tile_v * kCxStrip;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(
+        ana_image + (int64_t)chunk * 2 * plane);
+    uint4* dst = reinterpret_cast<uint4*>(Dh);
+    for (int i = tid; i < plane / 4; i += 512) dst[i] = src[i];
+    if (do_synth) {
+      const uint4* ssrc = reinterpret_cast<const uint4*>(
+          synp_image + (int64_t)chunk * 2 * splane);
+      uint4* sdst = reinterpret_cast<uint4*>(Sh);
+      for (int i = tid; i < splane / 4; i += 512) sdst[i] = ssrc[i];
+      for (int i = tid; i < 8 * K * WP; i += 512) priv[i] = 0.f;
+    }
+    const float* Rimg = R + img * g.H * (int64_t)g.W;
+    for (int e = tid; e < F::TH * kCxAnaPitch; e += 512) {
+      const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
+      const int y = u0 + ry, x = v0 + rx;
+      const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
+      const __bf16 h = (__bf16)v;
+      Rh[e] = cx_bits(h);
+      Rl[e] = cx_bits((__bf16)(v - (float)h));
+    }
+  }
+  __syncthreads();
+  stamp(0);
+  const int64_t map = (int64_t)g.ch * g.cw;
+  const unsigned map4 = (unsigned)(map * 4);
+  const int code_bytes = (int)((int64_t)g.s * map * 4);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Y + img * g.s * map), 0, code_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(C + img * g.s * map), 0, code_bytes, 0x00020000);
+  const bool ragged = (g.s % AC) != 0;
+  float* mine = priv + wave * K * WP;               // pixel rows u .. u+K-1
+  const int lu = wave;
+  const int u = u0 + lu;
+  if (u < g.ch) {
+    // tile t = (atom tile t >> 1, column tile t & 1), as in the analysis kernel
+    auto tile_offset = [&](int t) -> unsigned {
+      const int v = v0 + 32 * (t & 1) + l31;
+      const int a0 = chunk * AC + 32 * (t >> 1) + 4 * half;
+      return v < g.cw ? (unsigned)a0 * map4 + (unsigned)(u * g.cw + v) * 4u
+                      : 0x80000000u;
+    };
+    auto atoms_left = [&](int t) -> int {
+      return ragged ? g.s - (chunk * AC + 32 * (t >> 1) + 4 * half) : 64;
+    };
+    auto load_tile = [&](int t, float (&yv)[16], float (&cv)[16]) {
+      const unsigned lane_off = tile_offset(t);
+      const int left = atoms_left(t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const unsigned vo = rr < left ? lane_off : 0x80000000u;
+        yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            yrs, vo, (unsigned)rr * map4, 0));
+        cv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+            crs, vo, (unsigned)rr * map4, 0));
+      }
+    };
+    f32x16 Q[MT];
+    auto zero_q = [&]() {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Q[mt][r] = 0.f;
+    };
+    // proximal step on tile t; the new Y goes to memory and, as the B operand
+    // of the synthesis product, into Q
+    auto finish_tile = [&](int t, const float (&yv)[16], const float (&cv)[16],
+                           const f32x16& tile) {
+      const unsigned lane_off = tile_offset(t);
+      const int left = atoms_left(t);
+      float yn[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        const unsigned vo = rr < left ? lane_off : 0x80000000u;
+        const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
+        const float c = shrink(p, pp.cutoff, VTC_SOFT);
+        const float d = sub_rn(c, cv[r]);
+        const float y1 = add_rn(c, mul_rn(pp.beta, d));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1), yrs, vo,
+                                              (unsigned)rr * map4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), crs, vo,
+                                              (unsigned)rr * map4, 0);
+        // positions / atoms outside the problem contribute nothing
+        yn[r] = (vo != 0x80000000u) ? y1 : 0.f;
+      }
+      if (!do_synth) return;
+      const int ma = t >> 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = yn[8 * ks + j];
+        cx_bf16x8 bh, bl;
+        cx_split8(v8, bh, bl);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int off = (32 * mt + l31) * F::SYN_PITCH + 32 * ma + 16 * ks +
+                          8 * half;
+          const cx_bf16x8 ah = __builtin_bit_cast(
+              cx_bf16x8, *reinterpret_cast<const uint4*>(Sh + off));
+          const cx_bf16x8 al = __builtin_bit_cast(
+              cx_bf16x8, *reinterpret_cast<const uint4*>(Sl + off));
+          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, Q[mt], 0, 0, 0);
+          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, Q[mt], 0, 0, 0);
+          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, Q[mt], 0, 0, 0);
+        }
+      }
+    };
+    // col2im of Q (taps x 32 code columns of column tile ni) into the wave's
+    // window: register (mt, r) of lane half h holds tap idx + h * HTAPS at code
+    // column 32 ni + l31, i.e. pixel (dy + h * HROWS, 32 ni + l31 + dx); the dx
+    // sum is formed by lane rotation first (see conv_synth_x3_kernel)
+    auto fold = [&](int ni) {
+      const int pyb = half * Dm::HROWS;
+      const int pxb = 32 * ni + l31;
+      float* base = mine + pyb * WP + pxb;
+#pragma unroll
+      for (int dy = 0; dy < Dm::HROWS; ++dy) {
+        const bool row_ok = (pyb + dy) < K;
+        const bool spill_ok = row_ok && l31 < K - 1;
+        volatile float* pm = base + dy * WP;
+        volatile float* ps = base + dy * WP + 32;
+        float old_main = 0.f, old_spill = 0.f;
+        if (row_ok) old_main = *pm;
+        if (spill_ok) old_spill = *ps;
+        float main_sum = 0.f, spill_sum = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+          const int idx = dy * K + dx;                 // compile time
+          float rot = Q[idx / 16][idx % 16];
+          if (dx != 0) {
+            const int from = ((l31 - dx) & 31) | (lane & 32);
+            rot = __builtin_bit_cast(
+                float, __builtin_amdgcn_ds_bpermute(
+                           from * 4, __builtin_bit_cast(int, rot)));
+          }
+          if (l31 >= dx)
+            main_sum = add_rn(main_sum, rot);
+          else
+            spill_sum = add_rn(spill_sum, rot);
+        }
+        if (row_ok) *pm = add_rn(old_main, main_sum);
+        if (spill_ok) *ps = add_rn(old_spill, spill_sum);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    float yA[16], cA[16], yB[16], cB[16];
+    load_tile(0, yA, cA);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ma][ni][r] = 0.f;
+    for (int dy = 0; dy < K; ++dy) {
+      cx_bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int off = (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
+        const CxUnaligned16 h =
+            *reinterpret_cast<const CxUnaligned16*>(Rh + off);
+        const CxUnaligned16 l =
+            *reinterpret_cast<const CxUnaligned16*>(Rl + off);
+        bh[ni] = __builtin_bit_cast(cx_bf16x8, h);
+        bl[ni] = __builtin_bit_cast(cx_bf16x8, l);
+      }
+#pragma unroll
+      for (int ma = 0; ma < 2; ++ma) {
+        const int off = ((dy * AC + 32 * ma + l31) * 16) + 8 * half;
+        const cx_bf16x8 ah = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
+        const cx_bf16x8 al = __builtin_bit_cast(
+            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bh[ni], acc[ma][ni], 0, 0, 0);
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              ah, bl[ni], acc[ma][ni], 0, 0, 0);
+          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              al, bh[ni], acc[ma][ni], 0, 0, 0);
+        }
+      }
+    }
+    stamp(1);
+    // column tile 0: atom tiles 0, 1 (tiles t = 0, 2), then its fold; column
+    // tile 1: tiles t = 1, 3.  Loads of the next tile ahead of each finish.
+    zero_q();
+    load_tile(2, yB, cB);
+    finish_tile(0, yA, cA, acc[0][0]);
+    load_tile(1, yA, cA);
+    finish_tile(2, yB, cB, acc[1][0]);
+    stamp(2);
+    if (do_synth) {
+      fold(0);
+      zero_q();
+    }
+    stamp(3);
+    load_tile(3, yB, cB);
+    finish_tile(1, yA, cA, acc[0][1]);
+    finish_tile(3, yB, cB, acc[1][1]);
+    stamp(4);
+    if (do_synth) fold(1);
+    stamp(5);
+  }
+  if (stamps && lane == 0) {
+    for (int q = 0; q < 6; ++q) atomicAdd(stamps + q, st_acc[q]);
+    atomicAdd(stamps + 7, 1ull);
+  }
+  if (!do_synth) return;
+  __syncthreads();
+  // partial tile = the 8 windows added in wave order; window w covers pixel
+  // rows w .. w + K - 1 of the tile
+  float* out = partial + (((img * tiles_u + tile_u) * chunks + chunk) *
+                              (int64_t)tiles_v + tile_v) * (F::TH * F::TW);
+  for (int e = tid; e < F::TH * F::TW; e += 512) {
+    const int py = e / F::TW, px = e % F::TW;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const int ry = py - w;
+      if (ry >= 0 && ry < K) sum = add_rn(sum, priv[(w * K + ry) * WP + px]);
+    }
+    out[e] = sum;
+  }
+}
+
+// residual = mask * (sum of the partial tiles covering the pixel - image)
+template <int K>
+__global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
+                                           const float* __restrict__ X,
+                                           float* __restrict__ R, ConvGeo g,
+                                           int tiles_v, int tiles_u,
+                                           int chunks) {
+  using F = CxFused<K>;
+  const int64_t total = g.b * (int64_t)g.H * g.W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H);
+    const int64_t img = i / ((int64_t)g.W * g.H);
+    int tu_lo = (y - F::TH + F::ROWS) / F::ROWS;    // ceil((y - TH + 1) / ROWS)
+    if (y - F::TH + 1 <= 0) tu_lo = 0;
+    int tu_hi = y / F::ROWS;
+    if (tu_hi > tiles_u - 1) tu_hi = tiles_u - 1;
+    int tv_lo = (x - F::TW + kCxStrip) / kCxStrip;
+    if (x - F::TW + 1 <= 0) tv_lo = 0;
+    int tv_hi = x / kCxStrip;
+    if (tv_hi > tiles_v - 1) tv_hi = tiles_v - 1;
+    float sum = 0.f;
+    for (int tu = tu_lo; tu <= tu_hi; ++tu)
+      for (int c = 0; c < chunks; ++c)
+        for (int tv = tv_lo; tv <= tv_hi; ++tv) {
+          const float* tile = partial + (((img * tiles_u + tu) * chunks + c) *
+                                             (int64_t)tiles_v + tv) *
+                                            (F::TH * F::TW);
+          sum = add_rn(sum, tile[(y - tu * F::ROWS) * F::TW +
+                                 (x - tv * kCxStrip)]);
+        }
+    R[i] = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+  }
+}
+
 // ---------------------------------------------- dictionary gradient (a8/a9)
 // dD[s, dy, dx] = sum_{image, u, v} C[s, u, v] * r[u + dy, v + dx]
 // (dict_update_rules/convolutional/sc_steepest_descent.py:60-65) as a
@@ -665,6 +1039,8 @@ struct CxPlan {
   size_t syn_image_bytes, ana_image_bytes;
   size_t syn_lds, ana_lds;
   int th, tw;
+  // fused iteration kernel (conv_fused_x3_kernel): 0 when not applicable
+  size_t synp_image_bytes, partial_bytes, fused_lds;
 };
 
 static int cx_compute_units() {
@@ -735,6 +1111,14 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   p->ana_lds = (size_t)2 * K * p->AC * 16 * 2 +
                (size_t)2 * (p->ana_rows + K - 1) * kCxAnaPitch * 2;
   p->tw = Dm::TW;
+  using F = CxFused<K>;
+  p->synp_image_bytes = p->partial_bytes = p->fused_lds = 0;
+  if (p->AC == 64 && F::lds <= 160 * 1024) {
+    p->fused_lds = F::lds;
+    p->synp_image_bytes = (size_t)p->chunks * F::syn_bytes;
+    p->partial_bytes = (size_t)g.b * ceil_div(g.ch, F::ROWS) * p->chunks *
+                       ceil_div(g.cw, kCxStrip) * F::TH * F::TW * sizeof(float);
+  }
 }
 
 // Geometries this path covers: one channel, stride 1, square kernels of the
@@ -757,6 +1141,84 @@ static bool cx_plan(const ConvGeo& g, CxPlan* p) {
 
 static size_t cx_image_bytes(const CxPlan& p) {
   return align_up(p.syn_image_bytes, 256) + align_up(p.ana_image_bytes, 256);
+}
+
+// extra workspace of the fused iteration kernel
+static size_t cx_fused_bytes(const CxPlan& p) {
+  return align_up(p.synp_image_bytes, 256) + align_up(p.partial_bytes, 256);
+}
+
+template <int K>
+static int cx_launch_fused_k(const float* R, const uint16_t* ana,
+                             const uint16_t* synp, float* Y, float* C,
+                             float* partial, const float* X, float* R_next,
+                             const ConvGeo& g, const CxPlan& p,
+                             const ProxParams& pp, bool do_synth,
+                             hipStream_t st) {
+  using F = CxFused<K>;
+  const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
+  const int tiles_u = (int)ceil_div(g.ch, F::ROWS);
+  static unsigned long long attr_set = 0;
+  if (first_use_on_this_device(&attr_set)) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_fused_x3_kernel<K>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
+  const int64_t blocks = ceil_div(bands, 8) * 8 * tiles_v;
+  if (blocks > 0x7fffffffLL) {
+    set_error("conv bf16x3: too many tiles");
+    return VTC_ERR_INVALID_ARGUMENT;
+  }
+  static const bool want_stamps = getenv("VTC_CONV_STAMPS") != nullptr;
+  unsigned long long* stamps_dev = nullptr;
+  if (want_stamps) {
+    VTC_HIP_CHECK(hipMalloc(&stamps_dev, 64));
+    VTC_HIP_CHECK(hipMemsetAsync(stamps_dev, 0, 64, st));
+  }
+  hipLaunchKernelGGL(conv_fused_x3_kernel<K>, dim3((unsigned)blocks),
+                     dim3(512), F::lds, st, R, ana, synp, Y, C, partial, g,
+                     tiles_v, tiles_u, p.chunks, pp, do_synth ? 1 : 0,
+                     stamps_dev);
+  VTC_LAUNCH_CHECK();
+  if (stamps_dev) {
+    unsigned long long host[8];
+    VTC_HIP_CHECK(hipMemcpyAsync(host, stamps_dev, 64, hipMemcpyDeviceToHost, st));
+    VTC_HIP_CHECK(hipStreamSynchronize(st));
+    VTC_HIP_CHECK(hipFree(stamps_dev));
+    const char* names[6] = {"prologue", "analysis-mfma", "tiles0,2+synth",
+                            "fold0", "tiles1,3+synth", "fold1"};
+    for (int q = 0; q < 6; ++q)
+      fprintf(stderr, "[vtc conv stamps] %-15s %8.0f cycles/wave\n", names[q],
+              (double)host[q] / (double)host[7]);
+  }
+  if (do_synth) {
+    const int64_t pixels = g.b * (int64_t)g.H * g.W;
+    int64_t rblocks = ceil_div(pixels, 256);
+    if (rblocks > 65535) rblocks = 65535;
+    hipLaunchKernelGGL(conv_partial_reduce_kernel<K>, dim3((unsigned)rblocks),
+                       dim3(256), 0, st, partial, X, R_next, g, tiles_v,
+                       tiles_u, p.chunks);
+    VTC_LAUNCH_CHECK();
+  }
+  return VTC_OK;
+}
+
+// one fused iteration: (R, Y, C) -> (Y', C'), and R' unless it is the last one
+static int cx_launch_fused(const float* R, const uint16_t* ana,
+                           const uint16_t* synp, float* Y, float* C,
+                           float* partial, const float* X, float* R_next,
+                           const ConvGeo& g, const CxPlan& p,
+                           const ProxParams& pp, bool do_synth,
+                           hipStream_t st) {
+  switch (p.k) {
+    case 5: return cx_launch_fused_k<5>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
+    case 8: return cx_launch_fused_k<8>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
+    case 11: return cx_launch_fused_k<11>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
+    case 16: return cx_launch_fused_k<16>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
+  }
+  set_error("conv bf16x3: kernel size not instantiated");
+  return VTC_ERR_UNSUPPORTED;
 }
 
 static int cx_pack(const float* D, const ConvGeo& g, const CxPlan& p,
