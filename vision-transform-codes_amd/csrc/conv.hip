@@ -547,6 +547,8 @@ extern "C" int vtc_conv_ista_fista(
   uint16_t* ana_image = nullptr;
   uint16_t* synp_image = nullptr;   // fused iteration kernel (conv_x3.h)
   float* partial = nullptr;
+  float* Ypad = nullptr;            // padded-row code maps of that kernel
+  float* Cpad = nullptr;
   if (x3) {
     syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
@@ -557,6 +559,8 @@ extern "C" int vtc_conv_ista_fista(
         threshold == VTC_SOFT && early_stopping_epsilon < 0.f && !no_fused) {
       synp_image = ws.take<uint16_t>(xp.synp_image_bytes / 2);
       partial = ws.take<float>(xp.partial_bytes / sizeof(float));
+      Ypad = ws.take<float>(xp.padded_bytes / sizeof(float));
+      Cpad = ws.take<float>(xp.padded_bytes / sizeof(float));
       hipLaunchKernelGGL(conv_x3_pack_synp_kernel, dim3(256), dim3(256), 0, st,
                          dictionary, synp_image, g.s, xp.k, xp.slots,
                          xp.chunks);
@@ -614,15 +618,37 @@ extern "C" int vtc_conv_ista_fista(
                   fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr};
     if (x3 && synp_image) {
       // synthesis fused into the analysis epilogue: the residual of the first
-      // iteration from the stand-alone synthesis, the later ones from the
-      // partial tiles of the previous fused launch
+      // iteration from the stand-alone synthesis (on the caller's layout),
+      // the later ones from the partial tiles of the previous fused launch.
+      // Between the launches Y and the codes live in padded rows (conv_x3.h,
+      // CxMaps); the last launch writes the codes in the caller's layout.
       if (k == 0) {
-        rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
+        rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
+                             st);
         if (rc != VTC_OK) return rc;
+        if (initial_codes) {
+          const int64_t rows = (int64_t)g.b * g.s * g.ch;
+          hipLaunchKernelGGL(conv_pad_rows_kernel, dim3(4096), dim3(256), 0,
+                             st, initial_codes, Ypad, rows, (int)g.cw,
+                             xp.pitch);
+          hipLaunchKernelGGL(conv_pad_rows_kernel, dim3(4096), dim3(256), 0,
+                             st, initial_codes, Cpad, rows, (int)g.cw,
+                             xp.pitch);
+          VTC_LAUNCH_CHECK();
+        } else {
+          VTC_HIP_CHECK(hipMemsetAsync(Ypad, 0, xp.padded_bytes, st));
+          VTC_HIP_CHECK(hipMemsetAsync(Cpad, 0, xp.padded_bytes, st));
+        }
       }
-      rc = cx_launch_fused(residual, ana_image, synp_image, Y, codes, partial,
-                           images_padded, residual, g, xp, pp,
-                           k + 1 < num_iters, st);
+      const bool last = k + 1 == num_iters;
+      CxMaps maps;
+      maps.Y = Ypad;
+      maps.Cin = Cpad;
+      maps.Cout = last ? codes : Cpad;
+      maps.pitch = xp.pitch;
+      maps.out_pitch = last ? (int)g.cw : xp.pitch;
+      rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
+                           images_padded, residual, g, xp, pp, !last, st);
       if (rc != VTC_OK) return rc;
     } else if (x3) {
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);

@@ -287,15 +287,19 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
       float* base = mine + pyb * PW + pxb;
 #pragma unroll
       for (int dy = 0; dy < Dm::HROWS; ++dy) {
-        // plain read-modify-write (volatile keeps the order of this wave's
-        // LDS accesses; the two lanes groups never share a pixel): the
-        // reads are issued before the shuffles that produce the addends
+        // plain read-modify-write: within one pass no two lanes of the wave
+        // touch the same pixel (the half-waves sit on different image rows,
+        // main and spill columns are disjoint), and a lane's spill column of
+        // one column tile is the same lane's main column of the next, so
+        // program order per lane is all the ordering needed.  (Not volatile:
+        // a volatile access loses the LDS address space, becomes a flat
+        // load / store and drains vmcnt -- every outstanding code-map access.)
         const bool row_ok = (unsigned)(pyb + dy) < (unsigned)TH;
         const bool main_ok = row_ok && (unsigned)pxb < (unsigned)TW;
         const bool spill_ok =
             row_ok && l31 < K - 1 && (unsigned)(pxb + 32) < (unsigned)TW;
-        volatile float* pm = base + dy * PW;
-        volatile float* ps = base + dy * PW + 32;
+        float* pm = base + dy * PW;
+        float* ps = base + dy * PW + 32;
         float old_main = 0.f, old_spill = 0.f;
         if (main_ok) old_main = *pm;
         if (spill_ok) old_spill = *ps;
@@ -317,6 +321,10 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
         }
         if (main_ok) *pm = add_rn(old_main, main_sum);
         if (spill_ok) *ps = add_rn(old_spill, spill_sum);
+        // the half-waves of LATER passes do touch these pixels: keep the
+        // compiler from moving their reads above these writes (the LDS
+        // itself serves one wave's accesses in order)
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -547,30 +555,51 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
 // code column, register = atom), which -- with the atoms of a 16-atom k-step
 // taken in the order (j & 3) + 8 (j >> 2) + 4 half, baked into the packed
 // synthesis operand -- IS the B-operand layout of Q[tap, pos] = sum_s D[s, tap]
-// Y'[s, pos].  Each wave (one code row of the block's band of 8) forms Q for
-// its 64 code columns and its chunk of 64 atoms and folds it (col2im, as in
-// conv_synth_x3_kernel) into its private 11 x 74 window in LDS; the block adds
-// the 8 windows in wave order and writes ONE partial reconstruction tile
-// (18 x 74) to its own slot of a small buffer.  conv_partial_reduce_kernel
-// then sums, for every pixel, the <= 12 partial tiles that cover it in a fixed
-// order and forms the next residual.  Per iteration the code maps are read
-// twice and written twice, nothing else of that size moves.
+// Y'[s, pos].
+//
+// Blocks are persistent (one per CU, fixed chunk of 64 atoms: the operand
+// planes of both products go to LDS once) and walk items of 8 code rows x 32
+// code columns; wave w owns code row w of the item.  Per item a wave
+//   * forms the analysis product for its row (two 32x32 accumulator tiles),
+//   * finishes atom tile 0 (gradient step, threshold, extrapolation; Y' and the
+//     codes go to memory), issues the Y / code loads of the NEXT item's tile 0
+//     into the registers just freed, and feeds Y' to the synthesis product;
+//     the same for atom tile 1 -- every code-map load has most of an item of
+//     work between issue and use,
+//   * folds Q (col2im, as in conv_synth_x3_kernel) into its private 11 x 42
+//     window in LDS.
+// The block then adds the 8 windows in wave order and writes ONE partial
+// reconstruction tile (18 x 42) to its own slot of a small buffer;
+// conv_partial_reduce_kernel sums, for every pixel, the <= 12 partial tiles
+// that cover it in a fixed order and forms the next residual.  The residual
+// window of the next item is fetched a whole item ahead and the private
+// windows are double-buffered, which leaves one barrier per item.  Per
+// iteration the code maps are read twice and written twice, nothing else of
+// that size moves.
 // FISTA, soft threshold, no early stopping (the configuration of every
 // training run); other options take the two-kernel path.
 template <int K>
 struct CxFused {
-  static constexpr int ROWS = 8;                    // code rows per block
+  static constexpr int ROWS = 8;                    // code rows per item
+  static constexpr int COLS = 32;                   // code columns per item
   static constexpr int AC = 64;                     // atoms per chunk
-  static constexpr int WP = kCxStrip + K;           // window pitch (floats)
+  static constexpr int WIN_PITCH = 48;              // residual window row, bf16
+  static constexpr int WP = 48;                     // private window row, floats
   static constexpr int TH = ROWS + K - 1;           // partial tile rows
-  static constexpr int TW = kCxStrip + K - 1;       // partial tile columns
+  static constexpr int TW = COLS + K - 1;           // partial tile columns
   static constexpr int SYN_PITCH = AC + 8;          // elements per slot row
+  // partial tiles start on 128-byte lines (neighbouring tiles come from
+  // different blocks)
+  static constexpr int TILE_STRIDE = (TH * TW + 31) / 32 * 32;
+  static constexpr int WIN_ELEMS = TH * WIN_PITCH;  // one plane of one window
+  static constexpr int WIN_REGS = (WIN_ELEMS + 511) / 512;
   static constexpr size_t ana_bytes = (size_t)2 * K * AC * 16 * 2;
   static constexpr size_t syn_bytes =
       (size_t)2 * CxDims<K>::SLOTS * SYN_PITCH * 2;
-  static constexpr size_t win_bytes = (size_t)2 * TH * kCxAnaPitch * 2;
-  static constexpr size_t priv_bytes = (size_t)8 * K * WP * 4;
+  static constexpr size_t win_bytes = (size_t)2 * 2 * WIN_ELEMS * 2;
+  static constexpr size_t priv_bytes = (size_t)2 * ROWS * K * WP * 4;
   static constexpr size_t lds = ana_bytes + syn_bytes + win_bytes + priv_bytes;
+  static_assert(COLS + 15 < WIN_PITCH && TW <= WP, "window pitches");
 };
 
 // synp image (uint16): [chunk][plane][slot][AC + 8]: element a of a slot row
@@ -603,25 +632,46 @@ __global__ void conv_x3_pack_synp_kernel(const float* __restrict__ D,
   }
 }
 
-template <int K>
+// position of an item: image, first code row, first code column
+struct CxItem {
+  int img, u0, v0;
+  bool valid;
+};
+
+// Code maps of the fused path: rows padded to a multiple of 32 floats, so that
+// every (row, 32-column strip, atom) segment is exactly one 128-byte line and
+// no two items ever share a line.  (The maps are updated in place, and the L2s
+// of the 8 XCDs are not coherent within a launch: two blocks on different XCDs
+// read-modify-writing different parts of one line lose updates -- measured as
+// a ~10 % per-launch chance of a wrong 64-byte piece with unpadded rows.)
+struct CxMaps {
+  float* Y;            // momentum iterate, padded pitch, updated in place
+  const float* Cin;    // codes of the last iteration, padded pitch
+  float* Cout;         // new codes: Cin's buffer, or the caller's (b, s, ch, cw)
+  int pitch;           // floats per padded row
+  int out_pitch;       // floats per row of Cout
+};
+
+// RAGGED: the atom count is not a multiple of 64 (the last chunk is partial)
+// STAMP: per-section s_memtime sums (diagnostics, VTC_CONV_STAMPS=1)
+template <int K, bool RAGGED, bool STAMP>
 __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
-    const uint16_t* __restrict__ synp_image, float* __restrict__ Y,
-    float* __restrict__ C, float* __restrict__ partial, ConvGeo g, int tiles_v,
-    int tiles_u, int chunks, ProxParams pp, int do_synth,
-    unsigned long long* stamps) {
+    const uint16_t* __restrict__ synp_image, CxMaps M,
+    float* __restrict__ partial, ConvGeo g, int tiles_v, int tiles_u,
+    int chunks, ProxParams pp, int do_synth, unsigned long long* stamps) {
   using Dm = CxDims<K>;
   using F = CxFused<K>;
-  constexpr int AC = F::AC, MT = Dm::MT, WP = F::WP;
+  constexpr int AC = F::AC, MT = Dm::MT, WP = F::WP, WPITCH = F::WIN_PITCH;
   unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int slot_) {
-    if (!stamps) return;
+    if (!STAMP) return;
     unsigned long long now;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
     st_acc[slot_] += now - st_prev;
     st_prev = now;
   };
-  if (stamps)
+  if (STAMP)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
   extern __shared__ __attribute__((aligned(16))) char cx_lds[];
   const int plane = K * AC * 16;                    // analysis plane, elements
@@ -630,21 +680,63 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   const int splane = Dm::SLOTS * F::SYN_PITCH;      // synthesis plane
   uint16_t* Sh = Dl + plane;
   uint16_t* Sl = Sh + splane;
-  uint16_t* Rh = Sl + splane;
-  uint16_t* Rl = Rh + F::TH * kCxAnaPitch;
-  float* priv = reinterpret_cast<float*>(Rl + F::TH * kCxAnaPitch);
+  uint16_t* Win = Sl + splane;                      // [buffer][plane][TH][WPITCH]
+  float* Priv = reinterpret_cast<float*>(Win + 4 * F::WIN_ELEMS);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;       // wave = code row of the band
+  const int lane = tid & 63, wave = tid >> 6;       // wave = code row of the item
   const int l31 = lane & 31, half = lane >> 5;
-  // block -> (band, strip), XCD aware as in conv_analysis_x3_kernel
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tile_v = slot % tiles_v;
-  const int64_t band = (int64_t)(slot / tiles_v) * 8 + xcd;
-  if (band >= (int64_t)tiles_u * chunks * g.b) return;   // whole block
-  const int chunk = (int)(band % chunks);
-  const int tile_u = (int)((band / chunks) % tiles_u);
-  const int64_t img = band / ((int64_t)chunks * tiles_u);
-  const int u0 = tile_u * F::ROWS, v0 = tile_v * kCxStrip;
+  // Block -> (XCD, chunk, rank).  Workgroups go round-robin over the 8 XCDs;
+  // every strip of one band of rows is given to blocks of the SAME XCD: the
+  // residual windows of neighbouring strips overlap, and so do their partial
+  // tiles' readers.
+  const int xcd = blockIdx.x & 7;
+  const int local = blockIdx.x >> 3;                // index within the XCD
+  const int chunk = local % chunks;
+  const int rank = local / chunks;                  // among the blocks of
+  const int nper = (int)(gridDim.x >> 3) / chunks;  // this (XCD, chunk)
+  // bands of this XCD: band = 8 t + xcd, t = 0 .. bands_here - 1
+  const int bands = g.b * tiles_u;
+  const int bands_here = (bands - xcd + 7) / 8;
+  const int items = bands_here * tiles_v;           // host: fits 31 bits
+  auto decode = [&](int j) -> CxItem {
+    CxItem it;
+    it.valid = j < items;
+    const int jj = it.valid ? j : 0;
+    const int band = (jj / tiles_v) * 8 + xcd;
+    it.v0 = (jj % tiles_v) * F::COLS;
+    it.u0 = (band % tiles_u) * F::ROWS;
+    it.img = band / tiles_u;
+    return it;
+  };
+  CxItem cur = decode(rank);
+  if (!cur.valid) return;                           // whole block
+
+  // residual window of an item: global -> registers -> bf16 hi / lo planes
+  float wreg[F::WIN_REGS];
+  auto window_fetch = [&](const CxItem& it) {
+    if (!it.valid) return;
+    const float* Rimg = R + (int64_t)it.img * g.H * g.W;
+#pragma unroll
+    for (int q = 0; q < F::WIN_REGS; ++q) {
+      const int e = tid + 512 * q;
+      const int ry = e / WPITCH, rx = e % WPITCH;
+      const int y = it.u0 + ry, x = it.v0 + rx;
+      wreg[q] = (e < F::WIN_ELEMS && y < g.H && x < g.W)
+                    ? Rimg[y * (int)g.W + x] : 0.f;
+    }
+  };
+  auto window_store = [&](int buf) {
+    uint16_t* Wh = Win + buf * 2 * F::WIN_ELEMS;
+#pragma unroll
+    for (int q = 0; q < F::WIN_REGS; ++q) {
+      const int e = tid + 512 * q;
+      if (e < F::WIN_ELEMS) {
+        const __bf16 h = (__bf16)wreg[q];
+        Wh[e] = cx_bits(h);
+        Wh[F::WIN_ELEMS + e] = cx_bits((__bf16)(wreg[q] - (float)h));
+      }
+    }
+  };
   {
     const uint4* src = reinterpret_cast<const uint4*>(
         ana_image + (int64_t)chunk * 2 * plane);
@@ -655,225 +747,294 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
           synp_image + (int64_t)chunk * 2 * splane);
       uint4* sdst = reinterpret_cast<uint4*>(Sh);
       for (int i = tid; i < splane / 4; i += 512) sdst[i] = ssrc[i];
-      for (int i = tid; i < 8 * K * WP; i += 512) priv[i] = 0.f;
     }
-    const float* Rimg = R + img * g.H * (int64_t)g.W;
-    for (int e = tid; e < F::TH * kCxAnaPitch; e += 512) {
-      const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
-      const int y = u0 + ry, x = v0 + rx;
-      const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
-      const __bf16 h = (__bf16)v;
-      Rh[e] = cx_bits(h);
-      Rl[e] = cx_bits((__bf16)(v - (float)h));
-    }
+    window_fetch(cur);
+    window_store(0);
   }
   __syncthreads();
   stamp(0);
-  const int64_t map = (int64_t)g.ch * g.cw;
-  const unsigned map4 = (unsigned)(map * 4);
-  const int code_bytes = (int)((int64_t)g.s * map * 4);
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(Y + img * g.s * map), 0, code_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(C + img * g.s * map), 0, code_bytes, 0x00020000);
-  const bool ragged = (g.s % AC) != 0;
-  float* mine = priv + wave * K * WP;               // pixel rows u .. u+K-1
-  const int lu = wave;
-  const int u = u0 + lu;
-  if (u < g.ch) {
-    // tile t = (atom tile t >> 1, column tile t & 1), as in the analysis kernel
-    auto tile_offset = [&](int t) -> unsigned {
-      const int v = v0 + 32 * (t & 1) + l31;
-      const int a0 = chunk * AC + 32 * (t >> 1) + 4 * half;
-      return v < g.cw ? (unsigned)a0 * map4 + (unsigned)(u * g.cw + v) * 4u
-                      : 0x80000000u;
-    };
-    auto atoms_left = [&](int t) -> int {
-      return ragged ? g.s - (chunk * AC + 32 * (t >> 1) + 4 * half) : 64;
-    };
-    auto load_tile = [&](int t, float (&yv)[16], float (&cv)[16]) {
-      const unsigned lane_off = tile_offset(t);
-      const int left = atoms_left(t);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2);
-        const unsigned vo = rr < left ? lane_off : 0x80000000u;
-        yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            yrs, vo, (unsigned)rr * map4, 0));
-        cv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            crs, vo, (unsigned)rr * map4, 0));
-      }
-    };
-    f32x16 Q[MT];
-    auto zero_q = [&]() {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Q[mt][r] = 0.f;
-    };
-    // proximal step on tile t; the new Y goes to memory and, as the B operand
-    // of the synthesis product, into Q
-    auto finish_tile = [&](int t, const float (&yv)[16], const float (&cv)[16],
-                           const f32x16& tile) {
-      const unsigned lane_off = tile_offset(t);
-      const int left = atoms_left(t);
-      float yn[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2);
-        const unsigned vo = rr < left ? lane_off : 0x80000000u;
-        const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
-        const float c = shrink(p, pp.cutoff, VTC_SOFT);
-        const float d = sub_rn(c, cv[r]);
-        const float y1 = add_rn(c, mul_rn(pp.beta, d));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1), yrs, vo,
-                                              (unsigned)rr * map4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), crs, vo,
-                                              (unsigned)rr * map4, 0);
-        // positions / atoms outside the problem contribute nothing
-        yn[r] = (vo != 0x80000000u) ? y1 : 0.f;
-      }
-      if (!do_synth) return;
-      const int ma = t >> 1;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        float v8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = yn[8 * ks + j];
-        cx_bf16x8 bh, bl;
-        cx_split8(v8, bh, bl);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int off = (32 * mt + l31) * F::SYN_PITCH + 32 * ma + 16 * ks +
-                          8 * half;
-          const cx_bf16x8 ah = __builtin_bit_cast(
-              cx_bf16x8, *reinterpret_cast<const uint4*>(Sh + off));
-          const cx_bf16x8 al = __builtin_bit_cast(
-              cx_bf16x8, *reinterpret_cast<const uint4*>(Sl + off));
-          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, Q[mt], 0, 0, 0);
-          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, Q[mt], 0, 0, 0);
-          Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, Q[mt], 0, 0, 0);
-        }
-      }
-    };
-    // col2im of Q (taps x 32 code columns of column tile ni) into the wave's
-    // window: register (mt, r) of lane half h holds tap idx + h * HTAPS at code
-    // column 32 ni + l31, i.e. pixel (dy + h * HROWS, 32 ni + l31 + dx); the dx
-    // sum is formed by lane rotation first (see conv_synth_x3_kernel)
-    auto fold = [&](int ni) {
-      const int pyb = half * Dm::HROWS;
-      const int pxb = 32 * ni + l31;
-      float* base = mine + pyb * WP + pxb;
-#pragma unroll
-      for (int dy = 0; dy < Dm::HROWS; ++dy) {
-        const bool row_ok = (pyb + dy) < K;
-        const bool spill_ok = row_ok && l31 < K - 1;
-        volatile float* pm = base + dy * WP;
-        volatile float* ps = base + dy * WP + 32;
-        float old_main = 0.f, old_spill = 0.f;
-        if (row_ok) old_main = *pm;
-        if (spill_ok) old_spill = *ps;
-        float main_sum = 0.f, spill_sum = 0.f;
-#pragma unroll
-        for (int dx = 0; dx < K; ++dx) {
-          const int idx = dy * K + dx;                 // compile time
-          float rot = Q[idx / 16][idx % 16];
-          if (dx != 0) {
-            const int from = ((l31 - dx) & 31) | (lane & 32);
-            rot = __builtin_bit_cast(
-                float, __builtin_amdgcn_ds_bpermute(
-                           from * 4, __builtin_bit_cast(int, rot)));
-          }
-          if (l31 >= dx)
-            main_sum = add_rn(main_sum, rot);
-          else
-            spill_sum = add_rn(spill_sum, rot);
-        }
-        if (row_ok) *pm = add_rn(old_main, main_sum);
-        if (spill_ok) *ps = add_rn(old_spill, spill_sum);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
 
-    float yA[16], cA[16], yB[16], cB[16];
-    load_tile(0, yA, cA);
-    f32x16 acc[2][2];
+  // Buffer addressing of the code maps: lane offset (atom a0, row u, column v)
+  // + a scalar offset per register; positions outside the code map (and, on
+  // the ragged path, atoms outside the dictionary) get an out-of-range offset:
+  // loads give 0, stores are dropped.
+  const int64_t map = (int64_t)g.ch * M.pitch;       // padded map, floats
+  const unsigned map4 = (unsigned)(map * 4);
+  const int map_bytes = (int)((int64_t)g.s * map * 4);
+  const int64_t omap = (int64_t)g.ch * M.out_pitch;
+  const unsigned omap4 = (unsigned)(omap * 4);
+  const int omap_bytes = (int)((int64_t)g.s * omap * 4);
+  auto lane_offset = [&](const CxItem& it, int ma, int row_pitch,
+                         unsigned m4) -> unsigned {
+    const int u = it.u0 + wave, v = it.v0 + l31;
+    const int a0 = chunk * AC + 32 * ma + 4 * half;
+    return (it.valid && u < g.ch && v < g.cw)
+               ? (unsigned)a0 * m4 + (unsigned)(u * row_pitch + v) * 4u
+               : 0x80000000u;
+  };
+  auto atoms_left = [&](int ma) -> int {
+    return g.s - (chunk * AC + 32 * ma + 4 * half);
+  };
+  auto load_tile = [&](const CxItem& it, int ma, float (&yv)[16],
+                       float (&cv)[16]) {
+    if (!it.valid || it.u0 + wave >= g.ch) return;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(M.Y + it.img * g.s * map), 0, map_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(M.Cin + it.img * g.s * map), 0, map_bytes, 0x00020000);
+    const unsigned lane_off = lane_offset(it, ma, M.pitch, map4);
+    const int left = atoms_left(ma);
 #pragma unroll
-    for (int ma = 0; ma < 2; ++ma)
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      const unsigned vo = (!RAGGED || rr < left) ? lane_off : 0x80000000u;
+      yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+          yrs, vo, (unsigned)rr * map4, 0));
+      cv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+          crs, vo, (unsigned)rr * map4, 0));
+    }
+  };
+  // proximal step on atom tile ma of the current item, in registers: the new
+  // Y replaces the gradient in `tile` (zero where outside the problem, for the
+  // synthesis), the new codes replace the old ones in cv
+  auto prox_tile = [&](const CxItem& it, int ma, const float (&yv)[16],
+                       float (&cv)[16], f32x16& tile) {
+    const bool inside = lane_offset(it, ma, M.pitch, map4) != 0x80000000u;
+    const int left = atoms_left(ma);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
+      const float c = shrink(p, pp.cutoff, VTC_SOFT);
+      const float d = sub_rn(c, cv[r]);
+      const float y1 = add_rn(c, mul_rn(pp.beta, d));
+      cv[r] = c;
+      tile[r] = (inside && (!RAGGED || rr < left)) ? y1 : 0.f;
+    }
+  };
+  // (stores of dropped lanes carry the masked value: they go nowhere)
+  auto store_tile = [&](const CxItem& it, int ma, const f32x16& tile,
+                        const float (&cv)[16]) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(M.Y + it.img * g.s * map), 0, map_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(M.Cout + it.img * g.s * omap), 0, omap_bytes, 0x00020000);
+    const unsigned y_off = lane_offset(it, ma, M.pitch, map4);
+    const unsigned c_off = lane_offset(it, ma, M.out_pitch, omap4);
+    const int left = atoms_left(ma);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ma][ni][r] = 0.f;
-    for (int dy = 0; dy < K; ++dy) {
-      cx_bf16x8 bh[2], bl[2];
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      const bool ok = !RAGGED || rr < left;
+      __builtin_amdgcn_raw_buffer_store_b32(
+          __float_as_uint(tile[r]), yrs, ok ? y_off : 0x80000000u,
+          (unsigned)rr * map4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(
+          __float_as_uint(cv[r]), crs, ok ? c_off : 0x80000000u,
+          (unsigned)rr * omap4, 0);
+    }
+  };
+  f32x16 Q[MT];
+  // Q += D[chunk atoms of tile ma, taps]^T * Y' (Y' as the B operand).  The
+  // LDS reads of operand tile mt+1 are issued before the products of tile mt.
+  auto synth_tile = [&](int ma, const f32x16& yn) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int off = (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
-        const CxUnaligned16 h =
-            *reinterpret_cast<const CxUnaligned16*>(Rh + off);
-        const CxUnaligned16 l =
-            *reinterpret_cast<const CxUnaligned16*>(Rl + off);
-        bh[ni] = __builtin_bit_cast(cx_bf16x8, h);
-        bl[ni] = __builtin_bit_cast(cx_bf16x8, l);
-      }
+    for (int ks = 0; ks < 2; ++ks) {
+      float v8[8];
 #pragma unroll
-      for (int ma = 0; ma < 2; ++ma) {
-        const int off = ((dy * AC + 32 * ma + l31) * 16) + 8 * half;
-        const cx_bf16x8 ah = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
-        const cx_bf16x8 al = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+      for (int j = 0; j < 8; ++j) v8[j] = yn[8 * ks + j];
+      cx_bf16x8 bh, bl;
+      cx_split8(v8, bh, bl);
+      const int base = l31 * F::SYN_PITCH + 32 * ma + 16 * ks + 8 * half;
+      uint4 ah = *reinterpret_cast<const uint4*>(Sh + base);
+      uint4 al = *reinterpret_cast<const uint4*>(Sl + base);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bh[ni], acc[ma][ni], 0, 0, 0);
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bl[ni], acc[ma][ni], 0, 0, 0);
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              al, bh[ni], acc[ma][ni], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        uint4 ah_n = ah, al_n = al;
+        if (mt + 1 < MT) {
+          const int off = base + 32 * (mt + 1) * F::SYN_PITCH;
+          ah_n = *reinterpret_cast<const uint4*>(Sh + off);
+          al_n = *reinterpret_cast<const uint4*>(Sl + off);
         }
+        __builtin_amdgcn_sched_barrier(0);           // keep the reads up here
+        const cx_bf16x8 a_h = __builtin_bit_cast(cx_bf16x8, ah);
+        const cx_bf16x8 a_l = __builtin_bit_cast(cx_bf16x8, al);
+        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, Q[mt], 0, 0, 0);
+        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, Q[mt], 0, 0, 0);
+        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, Q[mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ah = ah_n;
+        al = al_n;
       }
     }
-    stamp(1);
-    // column tile 0: atom tiles 0, 1 (tiles t = 0, 2), then its fold; column
-    // tile 1: tiles t = 1, 3.  Loads of the next tile ahead of each finish.
-    zero_q();
-    load_tile(2, yB, cB);
-    finish_tile(0, yA, cA, acc[0][0]);
-    load_tile(1, yA, cA);
-    finish_tile(2, yB, cB, acc[1][0]);
-    stamp(2);
-    if (do_synth) {
-      fold(0);
-      zero_q();
+  };
+  // col2im of Q (taps x 32 code columns) into the wave's window: register
+  // (mt, r) of lane half h holds tap idx + h * HTAPS at code column l31, i.e.
+  // pixel (dy + h * HROWS, l31 + dx); the dx sum is formed by lane rotation
+  // first (see conv_synth_x3_kernel).  Within one fold no two lanes touch the
+  // same pixel, and nobody else touches this window until the barrier.
+  auto fold = [&](float* mine) {
+    const int pyb = half * Dm::HROWS;
+    float* base = mine + pyb * WP + l31;
+#pragma unroll
+    for (int dy = 0; dy < Dm::HROWS; ++dy) {
+      const bool row_ok = (pyb + dy) < K;
+      const bool spill_ok = row_ok && l31 < K - 1;
+      float* pm = base + dy * WP;
+      float* ps = base + dy * WP + 32;
+      float main_sum = 0.f, spill_sum = 0.f;
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) {
+        const int idx = dy * K + dx;                 // compile time
+        float rot = Q[idx / 16][idx % 16];
+        if (dx != 0) {
+          const int from = ((l31 - dx) & 31) | (lane & 32);
+          rot = __builtin_bit_cast(
+              float, __builtin_amdgcn_ds_bpermute(
+                         from * 4, __builtin_bit_cast(int, rot)));
+        }
+        if (l31 >= dx)
+          main_sum = add_rn(main_sum, rot);
+        else
+          spill_sum = add_rn(spill_sum, rot);
+      }
+      // the only fold of the item covers the whole window: plain stores
+      if (row_ok) *pm = main_sum;
+      if (spill_ok) *ps = spill_sum;
     }
-    stamp(3);
-    load_tile(3, yB, cB);
-    finish_tile(1, yA, cA, acc[0][1]);
-    finish_tile(3, yB, cB, acc[1][1]);
-    stamp(4);
-    if (do_synth) fold(1);
+  };
+
+  // analysis operands of tap row dy: the two window planes (8 consecutive
+  // pixels per lane, unaligned) and the kernel planes of both atom tiles
+  struct AnaOps {
+    uint4 bh, bl, ah0, al0, ah1, al1;
+  };
+  auto ana_load = [&](const uint16_t* Rh, const uint16_t* Rl, int dy) -> AnaOps {
+    AnaOps o;
+    const int boff = (wave + dy) * WPITCH + l31 + 8 * half;
+    o.bh = __builtin_bit_cast(
+        uint4, *reinterpret_cast<const CxUnaligned16*>(Rh + boff));
+    o.bl = __builtin_bit_cast(
+        uint4, *reinterpret_cast<const CxUnaligned16*>(Rl + boff));
+    const int off = (dy * AC + l31) * 16 + 8 * half;
+    o.ah0 = *reinterpret_cast<const uint4*>(Dh + off);
+    o.al0 = *reinterpret_cast<const uint4*>(Dl + off);
+    o.ah1 = *reinterpret_cast<const uint4*>(Dh + off + 32 * 16);
+    o.al1 = *reinterpret_cast<const uint4*>(Dl + off + 32 * 16);
+    return o;
+  };
+
+  float yA[16], cA[16], yB[16], cB[16];
+  load_tile(cur, 0, yA, cA);
+  load_tile(cur, 1, yB, cB);
+  CxItem nxt = decode(rank + nper);
+  window_fetch(nxt);
+  for (int i = 0; cur.valid; ++i) {
+    const int buf = i & 1;
+    const bool row_ok = cur.u0 + wave < g.ch;        // wave-uniform
+    const uint16_t* Rh = Win + buf * 2 * F::WIN_ELEMS;
+    const uint16_t* Rl = Rh + F::WIN_ELEMS;
+    if (row_ok) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ma][r] = 0.f;
+      // the LDS reads of tap row dy+1 are in flight under the products of dy
+      AnaOps ops = ana_load(Rh, Rl, 0);
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy) {
+        AnaOps nx = ops;
+        if (dy + 1 < K) nx = ana_load(Rh, Rl, dy + 1);
+        __builtin_amdgcn_sched_barrier(0);           // keep the reads up here
+        const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, ops.bh);
+        const cx_bf16x8 bl = __builtin_bit_cast(cx_bf16x8, ops.bl);
+        const cx_bf16x8 ah0 = __builtin_bit_cast(cx_bf16x8, ops.ah0);
+        const cx_bf16x8 al0 = __builtin_bit_cast(cx_bf16x8, ops.al0);
+        const cx_bf16x8 ah1 = __builtin_bit_cast(cx_bf16x8, ops.ah1);
+        const cx_bf16x8 al1 = __builtin_bit_cast(cx_bf16x8, ops.al1);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        ops = nx;
+      }
+      stamp(1);
+      if (do_synth) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Q[mt][r] = 0.f;
+      }
+      // Both proximal steps before any store: while loads and stores are
+      // mixed in flight every wait on a load drains the stores as well.  The
+      // products of tile 0's synthesis run under the arithmetic of tile 1;
+      // then stores, then the loads of the next item into the freed registers
+      // (most of an item of work between their issue and their use).
+      prox_tile(cur, 0, yA, cA, acc[0]);
+      if (do_synth) synth_tile(0, acc[0]);
+      prox_tile(cur, 1, yB, cB, acc[1]);
+      stamp(2);
+      store_tile(cur, 0, acc[0], cA);
+      store_tile(cur, 1, acc[1], cB);
+      load_tile(nxt, 0, yA, cA);
+      load_tile(nxt, 1, yB, cB);
+      if (do_synth) synth_tile(1, acc[1]);
+      stamp(3);
+      if (do_synth) fold(Priv + (buf * F::ROWS + wave) * K * WP);
+      stamp(4);
+    } else {
+      load_tile(nxt, 0, yA, cA);
+      load_tile(nxt, 1, yB, cB);
+    }
+    // the other window buffer was last read before the previous barrier
+    window_store(buf ^ 1);
+    const CxItem nn = decode(rank + (i + 2) * nper);
+    window_fetch(nn);
+    __syncthreads();
     stamp(5);
+    if (do_synth) {
+      // partial tile = the windows of the waves that had a code row, added in
+      // wave order; window w covers pixel rows w .. w + K - 1 of the tile
+      const float* pw = Priv + buf * F::ROWS * K * WP;
+      float* out = partial +
+                   ((((int64_t)(cur.img * tiles_u + cur.u0 / F::ROWS) * chunks +
+                      chunk) * tiles_v) + cur.v0 / F::COLS) * F::TILE_STRIDE;
+      for (int e = tid; e < F::TH * F::TW; e += 512) {
+        const int py = e / F::TW, px = e % F::TW;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < F::ROWS; ++w) {
+          const int ry = py - w;
+          if (ry >= 0 && ry < K && cur.u0 + w < g.ch)
+            sum = add_rn(sum, pw[(w * K + ry) * WP + px]);
+        }
+        out[e] = sum;
+      }
+    }
+    stamp(6);
+    cur = nxt;
+    nxt = nn;
   }
-  if (stamps && lane == 0) {
-    for (int q = 0; q < 6; ++q) atomicAdd(stamps + q, st_acc[q]);
+  if (STAMP && lane == 0) {
+    for (int q = 0; q < 7; ++q) atomicAdd(stamps + q, st_acc[q]);
     atomicAdd(stamps + 7, 1ull);
   }
-  if (!do_synth) return;
-  __syncthreads();
-  // partial tile = the 8 windows added in wave order; window w covers pixel
-  // rows w .. w + K - 1 of the tile
-  float* out = partial + (((img * tiles_u + tile_u) * chunks + chunk) *
-                              (int64_t)tiles_v + tile_v) * (F::TH * F::TW);
-  for (int e = tid; e < F::TH * F::TW; e += 512) {
-    const int py = e / F::TW, px = e % F::TW;
-    float sum = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      const int ry = py - w;
-      if (ry >= 0 && ry < K) sum = add_rn(sum, priv[(w * K + ry) * WP + px]);
-    }
-    out[e] = sum;
+}
+
+// (b, s, ch, cw) -> rows padded to `pitch` floats (pad columns untouched)
+__global__ void conv_pad_rows_kernel(const float* __restrict__ src,
+                                     float* __restrict__ dst, int64_t rows,
+                                     int cw, int pitch) {
+  const int64_t total = rows * cw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / cw;
+    const int col = (int)(i % cw);
+    dst[row * pitch + col] = src[i];
   }
 }
 
@@ -894,9 +1055,9 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
     if (y - F::TH + 1 <= 0) tu_lo = 0;
     int tu_hi = y / F::ROWS;
     if (tu_hi > tiles_u - 1) tu_hi = tiles_u - 1;
-    int tv_lo = (x - F::TW + kCxStrip) / kCxStrip;
+    int tv_lo = (x - F::TW + F::COLS) / F::COLS;
     if (x - F::TW + 1 <= 0) tv_lo = 0;
-    int tv_hi = x / kCxStrip;
+    int tv_hi = x / F::COLS;
     if (tv_hi > tiles_v - 1) tv_hi = tiles_v - 1;
     float sum = 0.f;
     for (int tu = tu_lo; tu <= tu_hi; ++tu)
@@ -904,9 +1065,9 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
         for (int tv = tv_lo; tv <= tv_hi; ++tv) {
           const float* tile = partial + (((img * tiles_u + tu) * chunks + c) *
                                              (int64_t)tiles_v + tv) *
-                                            (F::TH * F::TW);
+                                            F::TILE_STRIDE;
           sum = add_rn(sum, tile[(y - tu * F::ROWS) * F::TW +
-                                 (x - tv * kCxStrip)]);
+                                 (x - tv * F::COLS)]);
         }
     R[i] = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
   }
@@ -1041,6 +1202,8 @@ struct CxPlan {
   int th, tw;
   // fused iteration kernel (conv_fused_x3_kernel): 0 when not applicable
   size_t synp_image_bytes, partial_bytes, fused_lds;
+  int pitch;             // floats per padded code-map row
+  size_t padded_bytes;   // one padded set of code maps
 };
 
 static int cx_compute_units() {
@@ -1113,11 +1276,15 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   p->tw = Dm::TW;
   using F = CxFused<K>;
   p->synp_image_bytes = p->partial_bytes = p->fused_lds = 0;
-  if (p->AC == 64 && F::lds <= 160 * 1024) {
+  p->pitch = 0;
+  p->padded_bytes = 0;
+  if (p->AC == 64 && K <= 11 && F::lds <= 160 * 1024) {
     p->fused_lds = F::lds;
     p->synp_image_bytes = (size_t)p->chunks * F::syn_bytes;
     p->partial_bytes = (size_t)g.b * ceil_div(g.ch, F::ROWS) * p->chunks *
-                       ceil_div(g.cw, kCxStrip) * F::TH * F::TW * sizeof(float);
+                       ceil_div(g.cw, F::COLS) * F::TILE_STRIDE * sizeof(float);
+    p->pitch = (int)(ceil_div(g.cw, 32) * 32);
+    p->padded_bytes = (size_t)g.b * g.s * g.ch * p->pitch * sizeof(float);
   }
 }
 
@@ -1133,7 +1300,8 @@ static bool cx_plan(const ConvGeo& g, CxPlan* p) {
     default: return false;
   }
   // 32-bit byte offsets within one image's code maps (buffer addressing)
-  const int64_t code_bytes = (int64_t)p->s16 * g.ch * g.cw * 4;
+  const int64_t code_bytes =
+      (int64_t)p->s16 * g.ch * (ceil_div(g.cw, 32) * 32) * 4;
   return p->syn_rows > 0 && p->syn_lds <= 150 * 1024 &&
          p->ana_lds <= 150 * 1024 &&
          g.b <= 65535 && code_bytes < (int64_t)0x7fffffff;
@@ -1145,51 +1313,64 @@ static size_t cx_image_bytes(const CxPlan& p) {
 
 // extra workspace of the fused iteration kernel
 static size_t cx_fused_bytes(const CxPlan& p) {
-  return align_up(p.synp_image_bytes, 256) + align_up(p.partial_bytes, 256);
+  return align_up(p.synp_image_bytes, 256) + align_up(p.partial_bytes, 256) +
+         2 * align_up(p.padded_bytes, 256);
 }
 
-template <int K>
+template <int K, bool RAGGED>
 static int cx_launch_fused_k(const float* R, const uint16_t* ana,
-                             const uint16_t* synp, float* Y, float* C,
+                             const uint16_t* synp, const CxMaps& maps,
                              float* partial, const float* X, float* R_next,
                              const ConvGeo& g, const CxPlan& p,
                              const ProxParams& pp, bool do_synth,
                              hipStream_t st) {
   using F = CxFused<K>;
-  const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
+  const int tiles_v = (int)ceil_div(g.cw, F::COLS);
   const int tiles_u = (int)ceil_div(g.ch, F::ROWS);
   static unsigned long long attr_set = 0;
   if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_fused_x3_kernel<K>),
+        reinterpret_cast<const void*>(conv_fused_x3_kernel<K, RAGGED, false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(conv_fused_x3_kernel<K, RAGGED, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
-  const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
-  const int64_t blocks = ceil_div(bands, 8) * 8 * tiles_v;
-  if (blocks > 0x7fffffffLL) {
-    set_error("conv bf16x3: too many tiles");
-    return VTC_ERR_INVALID_ARGUMENT;
-  }
+  // persistent blocks, one per CU: the same number for every (XCD, chunk)
+  const int64_t bands = (int64_t)g.b * tiles_u;
+  const int64_t items_per_xcd = ceil_div(bands, 8) * tiles_v;
+  int64_t nper = cx_compute_units() / (8 * p.chunks);
+  if (nper < 1) nper = 1;
+  if (nper > items_per_xcd) nper = items_per_xcd;
+  const int64_t blocks = 8 * nper * p.chunks;
   static const bool want_stamps = getenv("VTC_CONV_STAMPS") != nullptr;
   unsigned long long* stamps_dev = nullptr;
   if (want_stamps) {
     VTC_HIP_CHECK(hipMalloc(&stamps_dev, 64));
     VTC_HIP_CHECK(hipMemsetAsync(stamps_dev, 0, 64, st));
   }
-  hipLaunchKernelGGL(conv_fused_x3_kernel<K>, dim3((unsigned)blocks),
-                     dim3(512), F::lds, st, R, ana, synp, Y, C, partial, g,
-                     tiles_v, tiles_u, p.chunks, pp, do_synth ? 1 : 0,
-                     stamps_dev);
+  if (stamps_dev)
+    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, true>),
+                       dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
+                       synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
+                       do_synth ? 1 : 0, stamps_dev);
+  else
+    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, false>),
+                       dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
+                       synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
+                       do_synth ? 1 : 0, nullptr);
   VTC_LAUNCH_CHECK();
   if (stamps_dev) {
     unsigned long long host[8];
     VTC_HIP_CHECK(hipMemcpyAsync(host, stamps_dev, 64, hipMemcpyDeviceToHost, st));
     VTC_HIP_CHECK(hipStreamSynchronize(st));
     VTC_HIP_CHECK(hipFree(stamps_dev));
-    const char* names[6] = {"prologue", "analysis-mfma", "tiles0,2+synth",
-                            "fold0", "tiles1,3+synth", "fold1"};
-    for (int q = 0; q < 6; ++q)
-      fprintf(stderr, "[vtc conv stamps] %-15s %8.0f cycles/wave\n", names[q],
+    const char* names[7] = {"setup", "analysis-mfma", "tile0+synth",
+                            "tile1+synth", "fold", "window+barrier",
+                            "partial-out"};
+    fprintf(stderr, "[vtc conv stamps] do_synth=%d\n", do_synth ? 1 : 0);
+    for (int q = 0; q < 7; ++q)
+      fprintf(stderr, "[vtc conv stamps] %-15s %8.0f ticks/wave\n", names[q],
               (double)host[q] / (double)host[7]);
   }
   if (do_synth) {
@@ -1206,17 +1387,25 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
 
 // one fused iteration: (R, Y, C) -> (Y', C'), and R' unless it is the last one
 static int cx_launch_fused(const float* R, const uint16_t* ana,
-                           const uint16_t* synp, float* Y, float* C,
+                           const uint16_t* synp, const CxMaps& maps,
                            float* partial, const float* X, float* R_next,
                            const ConvGeo& g, const CxPlan& p,
                            const ProxParams& pp, bool do_synth,
                            hipStream_t st) {
+#define VTC_CX_FUSED(KK)                                                       \
+  case KK:                                                                     \
+    return (g.s % 64) ? cx_launch_fused_k<KK, true>(R, ana, synp, maps,        \
+                                                    partial, X, R_next, g, p,  \
+                                                    pp, do_synth, st)          \
+                      : cx_launch_fused_k<KK, false>(R, ana, synp, maps,       \
+                                                     partial, X, R_next, g, p, \
+                                                     pp, do_synth, st)
   switch (p.k) {
-    case 5: return cx_launch_fused_k<5>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
-    case 8: return cx_launch_fused_k<8>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
-    case 11: return cx_launch_fused_k<11>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
-    case 16: return cx_launch_fused_k<16>(R, ana, synp, Y, C, partial, X, R_next, g, p, pp, do_synth, st);
+    VTC_CX_FUSED(5);
+    VTC_CX_FUSED(8);
+    VTC_CX_FUSED(11);
   }
+#undef VTC_CX_FUSED
   set_error("conv bf16x3: kernel size not instantiated");
   return VTC_ERR_UNSUPPORTED;
 }

@@ -279,12 +279,17 @@ __global__ __launch_bounds__(512) void fused_stream_kernel(StreamParams P) {
         // then the slot is free for phase q+2
         const char* src = Slots + (q & 1) * kSSlotBytes + w * 4096 + 16384 +
                           lane * 16;
-        float4 c[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          c[g] = *reinterpret_cast<const float4*>(src + g * 1024);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) out[(int64_t)q * 1024 + g * 64] = c[g];
+        // (named values, not an array: the array stayed in scratch memory
+        // and every copy paid a second, dead store through the same path)
+        const float4 c0 = *reinterpret_cast<const float4*>(src);
+        const float4 c1 = *reinterpret_cast<const float4*>(src + 1024);
+        const float4 c2 = *reinterpret_cast<const float4*>(src + 2048);
+        const float4 c3 = *reinterpret_cast<const float4*>(src + 3072);
+        float4* dst = out + (int64_t)q * 1024;
+        dst[0] = c0;
+        dst[64] = c1;
+        dst[128] = c2;
+        dst[192] = c3;
         if (q + 2 < nph) dma_phase(q + 2);
         prefetch_dict(q);
       }
