@@ -213,6 +213,13 @@ def test_bf16x3_modes_and_reproducibility(device, plugins):
     else:
       helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
                                  'bf16x3 %r' % kw, max_flip_mag=1e-5)
+  # a single iteration: the fused kernel's first launch is also its last
+  ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 1,
+                                  stepsize=eta)
+  out = conv.run(X, Dd, (1, 1), padding, 0.05, 1, stepsize=eta,
+                 precision='bf16x3')
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 2e-5,
+                             'bf16x3 one iteration', max_flip_mag=1e-5)
   warm = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 3,
                                    stepsize=eta)
   ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, 4,
@@ -270,6 +277,18 @@ def test_full_size_properties(device, plugins):
   again = conv.run(X, Dd, (1, 1), padding, 0.05, 12, stepsize=step,
                    precision='bf16x3')
   assert torch.equal(both, again)
+  # many short runs from non-zero codes, no threshold (every difference
+  # shows): the code maps are updated in place by blocks on 8 XCDs whose L2s
+  # are not coherent within a launch -- a layout in which two blocks share a
+  # cache line loses updates once in ~10 launches
+  rs = np.random.RandomState(7)
+  C0 = helpers.to_dev((0.01 * rs.randn(*both.shape)).astype(np.float32), device)
+  first = conv.run(X, Dd, (1, 1), padding, 0.0, 3, stepsize=step,
+                   precision='bf16x3', initial_codes=C0)
+  for _ in range(24):
+    rerun = conv.run(X, Dd, (1, 1), padding, 0.0, 3, stepsize=step,
+                     precision='bf16x3', initial_codes=C0)
+    assert torch.equal(first, rerun)
   for i in range(2):
     one = conv.run(X[i:i + 1].contiguous(), Dd, (1, 1), padding, 0.05, 12,
                    stepsize=step, precision='bf16x3')

@@ -620,33 +620,30 @@ extern "C" int vtc_conv_ista_fista(
       // synthesis fused into the analysis epilogue: the residual of the first
       // iteration from the stand-alone synthesis (on the caller's layout),
       // the later ones from the partial tiles of the previous fused launch.
-      // Between the launches Y and the codes live in padded rows (conv_x3.h,
-      // CxMaps); the last launch writes the codes in the caller's layout.
+      // Between the launches Y and the codes live in fragment order
+      // (conv_x3.h, CxMaps); the last launch writes the codes in the caller's
+      // layout.
       if (k == 0) {
         rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
                              st);
         if (rc != VTC_OK) return rc;
+        VTC_HIP_CHECK(hipMemsetAsync(Ypad, 0, xp.padded_bytes, st));
+        VTC_HIP_CHECK(hipMemsetAsync(Cpad, 0, xp.padded_bytes, st));
         if (initial_codes) {
-          const int64_t rows = (int64_t)g.b * g.s * g.ch;
-          hipLaunchKernelGGL(conv_pad_rows_kernel, dim3(4096), dim3(256), 0,
-                             st, initial_codes, Ypad, rows, (int)g.cw,
-                             xp.pitch);
-          hipLaunchKernelGGL(conv_pad_rows_kernel, dim3(4096), dim3(256), 0,
-                             st, initial_codes, Cpad, rows, (int)g.cw,
-                             xp.pitch);
+          const int tu = (int)ceil_div(g.ch, 8), tv = (int)ceil_div(g.cw, 32);
+          hipLaunchKernelGGL(conv_to_fragments_kernel, dim3(4096), dim3(256),
+                             0, st, initial_codes, Cpad, g, tu, tv, xp.chunks,
+                             8, 32);
           VTC_LAUNCH_CHECK();
-        } else {
-          VTC_HIP_CHECK(hipMemsetAsync(Ypad, 0, xp.padded_bytes, st));
-          VTC_HIP_CHECK(hipMemsetAsync(Cpad, 0, xp.padded_bytes, st));
+          VTC_HIP_CHECK(hipMemcpyAsync(Ypad, Cpad, xp.padded_bytes,
+                                       hipMemcpyDeviceToDevice, st));
         }
       }
       const bool last = k + 1 == num_iters;
       CxMaps maps;
       maps.Y = Ypad;
-      maps.Cin = Cpad;
-      maps.Cout = last ? codes : Cpad;
-      maps.pitch = xp.pitch;
-      maps.out_pitch = last ? (int)g.cw : xp.pitch;
+      maps.C = Cpad;
+      maps.user_codes = last ? codes : nullptr;
       rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
                            images_padded, residual, g, xp, pp, !last, st);
       if (rc != VTC_OK) return rc;

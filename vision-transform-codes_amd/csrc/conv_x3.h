@@ -593,13 +593,22 @@ struct CxFused {
   static constexpr int TILE_STRIDE = (TH * TW + 31) / 32 * 32;
   static constexpr int WIN_ELEMS = TH * WIN_PITCH;  // one plane of one window
   static constexpr int WIN_REGS = (WIN_ELEMS + 511) / 512;
+  // The window operand of a lane starts at pixel l31 + 8 half: a 16-byte LDS
+  // read at 2-byte alignment, which costs 52-64 LDS cycles per wave against 4
+  // for an aligned one (tools/micro/lds_unaligned.hip).  The window is kept
+  // in 4 copies, copy c shifted by c pixels, so that every lane reads two
+  // 8-byte aligned halves from the copy c = start & 3.  Copy stride = 2 planes
+  // + 32 elements: the 4 copies fall on disjoint LDS banks.
+  static constexpr int WIN_COPY = 2 * WIN_ELEMS + 32;
+  static constexpr int WIN_BUF = 4 * WIN_COPY;      // one window buffer, elements
   static constexpr size_t ana_bytes = (size_t)2 * K * AC * 16 * 2;
   static constexpr size_t syn_bytes =
       (size_t)2 * CxDims<K>::SLOTS * SYN_PITCH * 2;
-  static constexpr size_t win_bytes = (size_t)2 * 2 * WIN_ELEMS * 2;
+  static constexpr size_t win_bytes = (size_t)2 * WIN_BUF * 2;
   static constexpr size_t priv_bytes = (size_t)2 * ROWS * K * WP * 4;
   static constexpr size_t lds = ana_bytes + syn_bytes + win_bytes + priv_bytes;
-  static_assert(COLS + 15 < WIN_PITCH && TW <= WP, "window pitches");
+  static_assert(COLS + 15 < WIN_PITCH && TW <= WP && WIN_PITCH % 4 == 0,
+                "window pitches");
 };
 
 // synp image (uint16): [chunk][plane][slot][AC + 8]: element a of a slot row
@@ -638,19 +647,34 @@ struct CxItem {
   bool valid;
 };
 
-// Code maps of the fused path: rows padded to a multiple of 32 floats, so that
-// every (row, 32-column strip, atom) segment is exactly one 128-byte line and
-// no two items ever share a line.  (The maps are updated in place, and the L2s
-// of the 8 XCDs are not coherent within a launch: two blocks on different XCDs
-// read-modify-writing different parts of one line lose updates -- measured as
-// a ~10 % per-launch chance of a wrong 64-byte piece with unpadded rows.)
+// Code maps of the fused path ("fragment order").  Between the launches Y and
+// the codes are kept as the kernel's accumulator tiles: the 16 registers x 64
+// lanes of (item, chunk, code row, atom tile) form one 4 KB block,
+//   block = ((((img * tiles_u + tu) * tiles_v + tv) * chunks + chunk) * 8 + row)
+//           * 2 + atom tile
+//   float (r, lane) of a block at  (r >> 2) * 256 + lane * 4 + (r & 3),
+// so a tile moves with four 16-byte accesses per lane, 1 KB contiguous per
+// instruction (a quarter of the instructions of dword-per-lane accesses to the
+// (s, ch, cw) layout: a wave holds at most 64 vector-memory operations in
+// flight, and 128 per item made it wait on its own stores), and every block is
+// owned by one wave: no cache line is shared between blocks.  (The maps are
+// updated in place and the L2s of the 8 XCDs are not coherent within a
+// launch: with the (s, ch, cw) layout, whose rows are not multiples of 128
+// bytes, blocks on different XCDs read-modify-writing parts of one line lost
+// updates -- a ~10 % chance per launch of a wrong 64-byte piece.)
+// The caller's (b, s, ch, cw) layout appears at the two ends only: initial
+// codes are converted once, the last launch writes its codes in that layout.
 struct CxMaps {
-  float* Y;            // momentum iterate, padded pitch, updated in place
-  const float* Cin;    // codes of the last iteration, padded pitch
-  float* Cout;         // new codes: Cin's buffer, or the caller's (b, s, ch, cw)
-  int pitch;           // floats per padded row
-  int out_pitch;       // floats per row of Cout
+  float* Y;            // momentum iterate, fragment order, updated in place
+  float* C;            // codes of the last iteration, fragment order
+  float* user_codes;   // last launch: the caller's (b, s, ch, cw); else null
 };
+
+// floats of one fragment-order set of code maps
+static size_t cx_frag_floats(const ConvGeo& g, int chunks, int rows, int cols) {
+  return (size_t)g.b * ceil_div(g.ch, rows) * ceil_div(g.cw, cols) * chunks *
+         rows * 2 * 1024;
+}
 
 // RAGGED: the atom count is not a multiple of 64 (the last chunk is partial)
 // STAMP: per-section s_memtime sums (diagnostics, VTC_CONV_STAMPS=1)
@@ -659,11 +683,12 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     const uint16_t* __restrict__ synp_image, CxMaps M,
     float* __restrict__ partial, ConvGeo g, int tiles_v, int tiles_u,
-    int chunks, ProxParams pp, int do_synth, unsigned long long* stamps) {
+    int chunks, ProxParams pp, int do_synth, unsigned frag_bytes,
+    unsigned long long* stamps) {
   using Dm = CxDims<K>;
   using F = CxFused<K>;
   constexpr int AC = F::AC, MT = Dm::MT, WP = F::WP, WPITCH = F::WIN_PITCH;
-  unsigned long long st_prev = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = 0, st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int slot_) {
     if (!STAMP) return;
     unsigned long long now;
@@ -680,10 +705,13 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   const int splane = Dm::SLOTS * F::SYN_PITCH;      // synthesis plane
   uint16_t* Sh = Dl + plane;
   uint16_t* Sl = Sh + splane;
-  uint16_t* Win = Sl + splane;                      // [buffer][plane][TH][WPITCH]
-  float* Priv = reinterpret_cast<float*>(Win + 4 * F::WIN_ELEMS);
+  uint16_t* Win = Sl + splane;              // [buffer][copy][plane][TH][WPITCH]
+  float* Priv = reinterpret_cast<float*>(Win + 2 * F::WIN_BUF);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;       // wave = code row of the item
+  const int lane = tid & 63;
+  // wave = code row of the item; scalar, so that everything derived from it
+  // (block addresses of the code maps) stays in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   // Block -> (XCD, chunk, rank).  Workgroups go round-robin over the 8 XCDs;
   // every strip of one band of rows is given to blocks of the SAME XCD: the
@@ -726,14 +754,24 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     }
   };
   auto window_store = [&](int buf) {
-    uint16_t* Wh = Win + buf * 2 * F::WIN_ELEMS;
+    uint16_t* Wb = Win + buf * F::WIN_BUF;
 #pragma unroll
     for (int q = 0; q < F::WIN_REGS; ++q) {
       const int e = tid + 512 * q;
       if (e < F::WIN_ELEMS) {
         const __bf16 h = (__bf16)wreg[q];
-        Wh[e] = cx_bits(h);
-        Wh[F::WIN_ELEMS + e] = cx_bits((__bf16)(wreg[q] - (float)h));
+        const uint16_t hb = cx_bits(h);
+        const uint16_t lb = cx_bits((__bf16)(wreg[q] - (float)h));
+        const int rx = e % WPITCH;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          // pixel x of a row sits at position x - c of copy c; the first c
+          // pixels of a row are never the start of a copy-c read
+          if (rx >= c) {
+            Wb[c * F::WIN_COPY + e - c] = hb;
+            Wb[c * F::WIN_COPY + F::WIN_ELEMS + e - c] = lb;
+          }
+        }
       }
     }
   };
@@ -754,44 +792,35 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   __syncthreads();
   stamp(0);
 
-  // Buffer addressing of the code maps: lane offset (atom a0, row u, column v)
-  // + a scalar offset per register; positions outside the code map (and, on
-  // the ragged path, atoms outside the dictionary) get an out-of-range offset:
-  // loads give 0, stores are dropped.
-  const int64_t map = (int64_t)g.ch * M.pitch;       // padded map, floats
-  const unsigned map4 = (unsigned)(map * 4);
-  const int map_bytes = (int)((int64_t)g.s * map * 4);
-  const int64_t omap = (int64_t)g.ch * M.out_pitch;
-  const unsigned omap4 = (unsigned)(omap * 4);
-  const int omap_bytes = (int)((int64_t)g.s * omap * 4);
-  auto lane_offset = [&](const CxItem& it, int ma, int row_pitch,
-                         unsigned m4) -> unsigned {
-    const int u = it.u0 + wave, v = it.v0 + l31;
-    const int a0 = chunk * AC + 32 * ma + 4 * half;
-    return (it.valid && u < g.ch && v < g.cw)
-               ? (unsigned)a0 * m4 + (unsigned)(u * row_pitch + v) * 4u
-               : 0x80000000u;
-  };
-  auto atoms_left = [&](int ma) -> int {
-    return g.s - (chunk * AC + 32 * ma + 4 * half);
+  // fragment-order block of (item, this chunk, this wave's row, atom tile):
+  // byte offset, wave-uniform (the scalar offset of the buffer accesses; the
+  // lane part is lane * 16 for every access)
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)M.Y, 0, (int)frag_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)M.C, 0, (int)frag_bytes, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto block_of = [&](const CxItem& it, int ma) -> unsigned {
+    const int item_index =
+        (it.img * tiles_u + it.u0 / F::ROWS) * tiles_v + it.v0 / F::COLS;
+    return (unsigned)((((item_index * chunks + chunk) * F::ROWS + wave) * 2 +
+                       ma) * 4096);
   };
   auto load_tile = [&](const CxItem& it, int ma, float (&yv)[16],
                        float (&cv)[16]) {
     if (!it.valid || it.u0 + wave >= g.ch) return;  // wave-uniform
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(M.Y + it.img * g.s * map), 0, map_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(M.Cin + it.img * g.s * map), 0, map_bytes, 0x00020000);
-    const unsigned lane_off = lane_offset(it, ma, M.pitch, map4);
-    const int left = atoms_left(ma);
+    const unsigned blk = block_of(it, ma);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2);
-      const unsigned vo = (!RAGGED || rr < left) ? lane_off : 0x80000000u;
-      yv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-          yrs, vo, (unsigned)rr * map4, 0));
-      cv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-          crs, vo, (unsigned)rr * map4, 0));
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const cx_u32x4 y4 = __builtin_amdgcn_raw_buffer_load_b128(
+          yrs, lane16 + 1024u * k4, blk, 0);
+      const cx_u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(
+          crs, lane16 + 1024u * k4, blk, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        yv[4 * k4 + j] = __uint_as_float(y4[j]);
+        cv[4 * k4 + j] = __uint_as_float(c4[j]);
+      }
     }
   };
   // proximal step on atom tile ma of the current item, in registers: the new
@@ -799,8 +828,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   // synthesis), the new codes replace the old ones in cv
   auto prox_tile = [&](const CxItem& it, int ma, const float (&yv)[16],
                        float (&cv)[16], f32x16& tile) {
-    const bool inside = lane_offset(it, ma, M.pitch, map4) != 0x80000000u;
-    const int left = atoms_left(ma);
+    const bool inside = it.v0 + l31 < g.cw;          // the row is (row_ok)
+    const int left = g.s - (chunk * AC + 32 * ma + 4 * half);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
@@ -808,30 +837,49 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       const float c = shrink(p, pp.cutoff, VTC_SOFT);
       const float d = sub_rn(c, cv[r]);
       const float y1 = add_rn(c, mul_rn(pp.beta, d));
-      cv[r] = c;
-      tile[r] = (inside && (!RAGGED || rr < left)) ? y1 : 0.f;
+      const bool ok = inside && (!RAGGED || rr < left);
+      cv[r] = ok ? c : 0.f;
+      tile[r] = ok ? y1 : 0.f;
     }
   };
-  // (stores of dropped lanes carry the masked value: they go nowhere)
   auto store_tile = [&](const CxItem& it, int ma, const f32x16& tile,
                         const float (&cv)[16]) {
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(M.Y + it.img * g.s * map), 0, map_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(M.Cout + it.img * g.s * omap), 0, omap_bytes, 0x00020000);
-    const unsigned y_off = lane_offset(it, ma, M.pitch, map4);
-    const unsigned c_off = lane_offset(it, ma, M.out_pitch, omap4);
-    const int left = atoms_left(ma);
+    if (M.user_codes) {
+      // last launch: codes only, in the caller's layout (dword per lane:
+      // lane = column, register = atom)
+      const int64_t map = (int64_t)g.ch * g.cw;
+      const unsigned map4 = (unsigned)(map * 4);
+      const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(M.user_codes + it.img * g.s * map), 0,
+          (int)((int64_t)g.s * map * 4), 0x00020000);
+      const int u = it.u0 + wave, v = it.v0 + l31;
+      const int a0 = chunk * AC + 32 * ma + 4 * half;
+      const unsigned off = v < g.cw ? (unsigned)a0 * map4 +
+                                          (unsigned)(u * (int)g.cw + v) * 4u
+                                    : 0x80000000u;
+      const int left = g.s - a0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rr = (r & 3) + 8 * (r >> 2);
-      const bool ok = !RAGGED || rr < left;
-      __builtin_amdgcn_raw_buffer_store_b32(
-          __float_as_uint(tile[r]), yrs, ok ? y_off : 0x80000000u,
-          (unsigned)rr * map4, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(
-          __float_as_uint(cv[r]), crs, ok ? c_off : 0x80000000u,
-          (unsigned)rr * omap4, 0);
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2);
+        __builtin_amdgcn_raw_buffer_store_b32(
+            __float_as_uint(cv[r]), crs,
+            (!RAGGED || rr < left) ? off : 0x80000000u, (unsigned)rr * map4, 0);
+      }
+      return;
+    }
+    const unsigned blk = block_of(it, ma);
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      cx_u32x4 y4, c4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        y4[j] = __float_as_uint(tile[4 * k4 + j]);
+        c4[j] = __float_as_uint(cv[4 * k4 + j]);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(y4, yrs, lane16 + 1024u * k4, blk,
+                                             0);
+      __builtin_amdgcn_raw_buffer_store_b128(c4, crs, lane16 + 1024u * k4, blk,
+                                             0);
     }
   };
   f32x16 Q[MT];
@@ -874,6 +922,11 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   // first (see conv_synth_x3_kernel).  Within one fold no two lanes touch the
   // same pixel, and nobody else touches this window until the barrier.
   auto fold = [&](float* mine) {
+    // (opaque to the optimiser: otherwise the K - 1 rotation addresses are
+    // hoisted out of the item loop and held in registers the loop needs)
+    int lane4 = l31 * 4;
+    asm volatile("" : "+v"(lane4));
+    const int half_bit = (lane & 32) * 4;
     const int pyb = half * Dm::HROWS;
     float* base = mine + pyb * WP + l31;
 #pragma unroll
@@ -888,10 +941,10 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
         const int idx = dy * K + dx;                 // compile time
         float rot = Q[idx / 16][idx % 16];
         if (dx != 0) {
-          const int from = ((l31 - dx) & 31) | (lane & 32);
+          const int from4 = ((lane4 - 4 * dx) & 124) | half_bit;
           rot = __builtin_bit_cast(
               float, __builtin_amdgcn_ds_bpermute(
-                         from * 4, __builtin_bit_cast(int, rot)));
+                         from4, __builtin_bit_cast(int, rot)));
         }
         if (l31 >= dx)
           main_sum = add_rn(main_sum, rot);
@@ -909,13 +962,17 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   struct AnaOps {
     uint4 bh, bl, ah0, al0, ah1, al1;
   };
-  auto ana_load = [&](const uint16_t* Rh, const uint16_t* Rl, int dy) -> AnaOps {
+  const int win_start = l31 + 8 * half;             // first pixel of the lane
+  const int win_lane = (win_start & 3) * F::WIN_COPY + (win_start & ~3);
+  auto ana_load = [&](const uint16_t* Wb, int dy) -> AnaOps {
     AnaOps o;
-    const int boff = (wave + dy) * WPITCH + l31 + 8 * half;
-    o.bh = __builtin_bit_cast(
-        uint4, *reinterpret_cast<const CxUnaligned16*>(Rh + boff));
-    o.bl = __builtin_bit_cast(
-        uint4, *reinterpret_cast<const CxUnaligned16*>(Rl + boff));
+    const uint16_t* bp = Wb + win_lane + (wave + dy) * WPITCH;
+    const uint2 h0 = *reinterpret_cast<const uint2*>(bp);
+    const uint2 h1 = *reinterpret_cast<const uint2*>(bp + 4);
+    const uint2 l0 = *reinterpret_cast<const uint2*>(bp + F::WIN_ELEMS);
+    const uint2 l1 = *reinterpret_cast<const uint2*>(bp + F::WIN_ELEMS + 4);
+    o.bh = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    o.bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
     const int off = (dy * AC + l31) * 16 + 8 * half;
     o.ah0 = *reinterpret_cast<const uint4*>(Dh + off);
     o.al0 = *reinterpret_cast<const uint4*>(Dl + off);
@@ -932,8 +989,13 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   for (int i = 0; cur.valid; ++i) {
     const int buf = i & 1;
     const bool row_ok = cur.u0 + wave < g.ch;        // wave-uniform
-    const uint16_t* Rh = Win + buf * 2 * F::WIN_ELEMS;
-    const uint16_t* Rl = Rh + F::WIN_ELEMS;
+    const uint16_t* Wb = Win + buf * F::WIN_BUF;
+    // The window of the NEXT item goes to the other buffer now: it was last
+    // read before the previous barrier, and everything this wave has in
+    // flight (the next window, this item's code maps) was issued most of an
+    // item ago -- the one full wait on memory per item costs nothing here.
+    window_store(buf ^ 1);
+    const CxItem nn = decode(rank + (i + 2) * nper);
     if (row_ok) {
       f32x16 acc[2];
 #pragma unroll
@@ -941,11 +1003,11 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ma][r] = 0.f;
       // the LDS reads of tap row dy+1 are in flight under the products of dy
-      AnaOps ops = ana_load(Rh, Rl, 0);
+      AnaOps ops = ana_load(Wb, 0);
 #pragma unroll
       for (int dy = 0; dy < K; ++dy) {
         AnaOps nx = ops;
-        if (dy + 1 < K) nx = ana_load(Rh, Rl, dy + 1);
+        if (dy + 1 < K) nx = ana_load(Wb, dy + 1);
         __builtin_amdgcn_sched_barrier(0);           // keep the reads up here
         const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, ops.bh);
         const cx_bf16x8 bl = __builtin_bit_cast(cx_bf16x8, ops.bl);
@@ -962,6 +1024,7 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
         __builtin_amdgcn_sched_barrier(0);
         ops = nx;
       }
+      window_fetch(nn);                              // for the item after next
       stamp(1);
       if (do_synth) {
 #pragma unroll
@@ -980,20 +1043,19 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       stamp(2);
       store_tile(cur, 0, acc[0], cA);
       store_tile(cur, 1, acc[1], cB);
+      stamp(7);
       load_tile(nxt, 0, yA, cA);
       load_tile(nxt, 1, yB, cB);
+      stamp(8);
       if (do_synth) synth_tile(1, acc[1]);
       stamp(3);
       if (do_synth) fold(Priv + (buf * F::ROWS + wave) * K * WP);
       stamp(4);
     } else {
+      window_fetch(nn);
       load_tile(nxt, 0, yA, cA);
       load_tile(nxt, 1, yB, cB);
     }
-    // the other window buffer was last read before the previous barrier
-    window_store(buf ^ 1);
-    const CxItem nn = decode(rank + (i + 2) * nper);
-    window_fetch(nn);
     __syncthreads();
     stamp(5);
     if (do_synth) {
@@ -1020,21 +1082,40 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     nxt = nn;
   }
   if (STAMP && lane == 0) {
-    for (int q = 0; q < 7; ++q) atomicAdd(stamps + q, st_acc[q]);
-    atomicAdd(stamps + 7, 1ull);
+    for (int q = 0; q < 9; ++q) atomicAdd(stamps + q, st_acc[q]);
+    atomicAdd(stamps + 9, 1ull);
   }
 }
 
-// (b, s, ch, cw) -> rows padded to `pitch` floats (pad columns untouched)
-__global__ void conv_pad_rows_kernel(const float* __restrict__ src,
-                                     float* __restrict__ dst, int64_t rows,
-                                     int cw, int pitch) {
-  const int64_t total = rows * cw;
+// (b, s, ch, cw) -> fragment order (positions outside the maps stay as they
+// are: the destination is zeroed beforehand).  One thread per destination
+// float4 = 4 atoms (a0 + 8 k + 4 half + j, j = 0..3) of one position.
+__global__ void conv_to_fragments_kernel(const float* __restrict__ src,
+                                         float* __restrict__ dst, ConvGeo g,
+                                         int tiles_u, int tiles_v, int chunks,
+                                         int rows, int cols) {
+  const int64_t total = (int64_t)g.b * tiles_u * tiles_v * chunks * rows * 2 * 256;
+  const int64_t map = (int64_t)g.ch * g.cw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / cw;
-    const int col = (int)(i % cw);
-    dst[row * pitch + col] = src[i];
+    const int lane = (int)(i & 63), k4 = (int)((i >> 6) & 3);
+    int64_t rest = i >> 8;
+    const int ma = (int)(rest & 1); rest >>= 1;
+    const int row = (int)(rest % rows); rest /= rows;
+    const int chunk = (int)(rest % chunks); rest /= chunks;
+    const int tv = (int)(rest % tiles_v); rest /= tiles_v;
+    const int tu = (int)(rest % tiles_u);
+    const int64_t img = rest / tiles_u;
+    const int u = tu * rows + row, v = tv * cols + (lane & 31);
+    if (u >= g.ch || v >= g.cw) continue;
+    const int a0 = chunk * 64 + 32 * ma + 8 * k4 + 4 * (lane >> 5);
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p = src + (img * g.s + a0) * map + (int64_t)u * g.cw + v;
+    if (a0 + 0 < g.s) out.x = p[0];
+    if (a0 + 1 < g.s) out.y = p[map];
+    if (a0 + 2 < g.s) out.z = p[2 * map];
+    if (a0 + 3 < g.s) out.w = p[3 * map];
+    reinterpret_cast<float4*>(dst)[i] = out;
   }
 }
 
@@ -1202,8 +1283,7 @@ struct CxPlan {
   int th, tw;
   // fused iteration kernel (conv_fused_x3_kernel): 0 when not applicable
   size_t synp_image_bytes, partial_bytes, fused_lds;
-  int pitch;             // floats per padded code-map row
-  size_t padded_bytes;   // one padded set of code maps
+  size_t padded_bytes;   // one fragment-order set of code maps
 };
 
 static int cx_compute_units() {
@@ -1276,15 +1356,14 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   p->tw = Dm::TW;
   using F = CxFused<K>;
   p->synp_image_bytes = p->partial_bytes = p->fused_lds = 0;
-  p->pitch = 0;
   p->padded_bytes = 0;
   if (p->AC == 64 && K <= 11 && F::lds <= 160 * 1024) {
     p->fused_lds = F::lds;
     p->synp_image_bytes = (size_t)p->chunks * F::syn_bytes;
     p->partial_bytes = (size_t)g.b * ceil_div(g.ch, F::ROWS) * p->chunks *
                        ceil_div(g.cw, F::COLS) * F::TILE_STRIDE * sizeof(float);
-    p->pitch = (int)(ceil_div(g.cw, 32) * 32);
-    p->padded_bytes = (size_t)g.b * g.s * g.ch * p->pitch * sizeof(float);
+    p->padded_bytes =
+        cx_frag_floats(g, p->chunks, F::ROWS, F::COLS) * sizeof(float);
   }
 }
 
@@ -1300,8 +1379,7 @@ static bool cx_plan(const ConvGeo& g, CxPlan* p) {
     default: return false;
   }
   // 32-bit byte offsets within one image's code maps (buffer addressing)
-  const int64_t code_bytes =
-      (int64_t)p->s16 * g.ch * (ceil_div(g.cw, 32) * 32) * 4;
+  const int64_t code_bytes = (int64_t)p->s16 * g.ch * g.cw * 4;
   return p->syn_rows > 0 && p->syn_lds <= 150 * 1024 &&
          p->ana_lds <= 150 * 1024 &&
          g.b <= 65535 && code_bytes < (int64_t)0x7fffffff;
@@ -1346,32 +1424,32 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
   static const bool want_stamps = getenv("VTC_CONV_STAMPS") != nullptr;
   unsigned long long* stamps_dev = nullptr;
   if (want_stamps) {
-    VTC_HIP_CHECK(hipMalloc(&stamps_dev, 64));
-    VTC_HIP_CHECK(hipMemsetAsync(stamps_dev, 0, 64, st));
+    VTC_HIP_CHECK(hipMalloc(&stamps_dev, 80));
+    VTC_HIP_CHECK(hipMemsetAsync(stamps_dev, 0, 80, st));
   }
   if (stamps_dev)
     hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, true>),
                        dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
                        synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
-                       do_synth ? 1 : 0, stamps_dev);
+                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, stamps_dev);
   else
     hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, false>),
                        dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
                        synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
-                       do_synth ? 1 : 0, nullptr);
+                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, nullptr);
   VTC_LAUNCH_CHECK();
   if (stamps_dev) {
-    unsigned long long host[8];
-    VTC_HIP_CHECK(hipMemcpyAsync(host, stamps_dev, 64, hipMemcpyDeviceToHost, st));
+    unsigned long long host[10];
+    VTC_HIP_CHECK(hipMemcpyAsync(host, stamps_dev, 80, hipMemcpyDeviceToHost, st));
     VTC_HIP_CHECK(hipStreamSynchronize(st));
     VTC_HIP_CHECK(hipFree(stamps_dev));
-    const char* names[7] = {"setup", "analysis-mfma", "tile0+synth",
-                            "tile1+synth", "fold", "window+barrier",
-                            "partial-out"};
+    const char* names[9] = {"setup", "window+analysis", "prox A, B + synth A",
+                            "synth B", "fold", "barrier", "partial-out",
+                            "stores", "loads"};
     fprintf(stderr, "[vtc conv stamps] do_synth=%d\n", do_synth ? 1 : 0);
-    for (int q = 0; q < 7; ++q)
-      fprintf(stderr, "[vtc conv stamps] %-15s %8.0f ticks/wave\n", names[q],
-              (double)host[q] / (double)host[7]);
+    for (int q = 0; q < 9; ++q)
+      fprintf(stderr, "[vtc conv stamps] %-20s %8.0f ticks/wave\n", names[q],
+              (double)host[q] / (double)host[9]);
   }
   if (do_synth) {
     const int64_t pixels = g.b * (int64_t)g.H * g.W;
