@@ -30,6 +30,15 @@ run_pmc st1 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 run_pmc st2 FETCH_SIZE -- python3 tools/run_subspace_once.py
 run_pmc st3 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 tools/run_subspace_once.py
 python3 tools/pmc_summary.py $out fused_stream_kernel > $out/stream_pmc.txt; cat $out/stream_pmc.txt
+echo "== PMC passes, fused conv kernel (configs[4], b = 8, 20 iterations)"
+run_pmc cv1 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 tools/run_configs.py conv
+run_pmc cv2 FETCH_SIZE -- python3 tools/run_configs.py conv
+run_pmc cv3 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python3 tools/run_configs.py conv
+run_pmc cv4 SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS -- python3 tools/run_configs.py conv
+python3 tools/pmc_summary.py $out conv_ > $out/conv_pmc.txt; cat $out/conv_pmc.txt
+VTC_CONV_STAMPS=1 timeout -k 10 100 python3 tools/run_configs.py conv 2>&1 | grep -A10 "do_synth=1" | tail -11 > $out/conv_stamps.txt; cat $out/conv_stamps.txt
+[ -x tools/micro/lds_unaligned ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/lds_unaligned.hip -o tools/micro/lds_unaligned 2>/dev/null
+timeout -k 10 60 tools/micro/lds_unaligned > $out/lds_unaligned.txt 2>&1; cat $out/lds_unaligned.txt
 echo "== example sizes"
 timeout -k 10 200 python3 tools/time_fc_example.py 2>&1 | grep -v amdgpu > $out/example_sizes.txt
 timeout -k 10 200 python3 tools/time_conv_example.py 2>&1 | grep -v amdgpu >> $out/example_sizes.txt; cat $out/example_sizes.txt
