@@ -213,10 +213,19 @@ static AnaPlan plan_analysis(const ConvGeo& g) {
   return p;
 }
 
+// y_out / c_out: where the two-kernel analysis routes write the new momentum
+// iterate and the new codes.  Never the buffers they read: the maps are in
+// the caller's (b, s, ch, cw) layout, whose rows are not multiples of 128
+// bytes, so blocks on different XCDs share cache lines -- and a line that two
+// XCDs both read and partly rewrite within one launch can lose one of the
+// updates (the L2s are not coherent within a launch).  Lines
+// that are only written merge correctly.
 struct ProxParams {
   float eta, cutoff, beta;
   int mode, fista;
   double* delta_sum;
+  float* y_out;
+  float* c_out;
 };
 
 }  // namespace vtc
@@ -283,11 +292,11 @@ __global__ __launch_bounds__(256) void conv_analysis_prox_kernel(
         float d;
         if (pp.fista) {
           d = sub_rn(c, C[idx]);
-          Y[idx] = add_rn(c, mul_rn(pp.beta, d));
+          pp.y_out[idx] = add_rn(c, mul_rn(pp.beta, d));
         } else {
           d = sub_rn(c, yv);
         }
-        C[idx] = c;
+        pp.c_out[idx] = c;
         if (pp.delta_sum) local += (double)(fabsf(d) / pp.eta);
       }
     }
@@ -445,7 +454,7 @@ static size_t conv_x3_image_bytes(const ConvGeo& g) {
 static size_t conv_inference_ws(const ConvGeo& g) {
   const size_t code_elems = (size_t)g.b * g.s * g.ch * g.cw;
   const size_t img_elems = (size_t)g.b * g.c * g.H * g.W;
-  return align_up(code_elems * sizeof(float), 256) +          // Y
+  return 3 * align_up(code_elems * sizeof(float), 256) +      // Y, Y', C'
          align_up(8 * img_elems * sizeof(float), 256) +       // residual or
                                                               // <= 8 partials
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
@@ -541,6 +550,8 @@ extern "C" int vtc_conv_ista_fista(
   const int ctaps = g.c * g.kh * g.kw;
   Carver ws(workspace);
   float* Ybuf = ws.take<float>(code_elems);
+  float* Yalt = ws.take<float>(code_elems);   // out-of-place targets of the
+  float* Calt = ws.take<float>(code_elems);   // two-kernel routes (ProxParams)
   float* residual = ws.take<float>(8 * img_elems);
   float* Kt = ws.take<float>((size_t)g.s * ctaps);
   uint16_t* syn_image = nullptr;
@@ -611,11 +622,17 @@ extern "C" int vtc_conv_ista_fista(
   std::vector<float> betas;
   fista_betas(num_iters, &betas);
   int done = 0;
+  // two-kernel routes: (Y, C) -> (y_out, c_out), buffers swapped per iteration
+  float* Cin = codes;
+  float* Cout = Calt;
+  float* Yout = Yalt;
   for (int k = 0; k < num_iters; ++k) {
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
+    if (!fista) Y = Cin;                        // ISTA iterates on the codes
     ProxParams pp{eta, cutoff, fista ? betas[k] : 0.f, threshold,
-                  fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr};
+                  fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr,
+                  Yout, Cout};
     if (x3 && synp_image) {
       // synthesis fused into the analysis epilogue: the residual of the first
       // iteration from the stand-alone synthesis (on the caller's layout),
@@ -650,14 +667,14 @@ extern "C" int vtc_conv_ista_fista(
     } else if (x3) {
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
       if (rc != VTC_OK) return rc;
-      rc = cx_launch_analysis(residual, ana_image, Y, codes, g, xp, pp, st);
+      rc = cx_launch_analysis(residual, ana_image, Y, Cin, g, xp, pp, st);
       if (rc != VTC_OK) return rc;
     } else if (patch_path) {
       // strides > 1: both convolutions as exact-f32 patch contractions
       rc = patch_synthesis(Y, dictionary, images_padded, residual,
                            contributions, g, st);
       if (rc != VTC_OK) return rc;
-      rc = patch_analysis(residual, dictionary, Y, codes, patches, g, pp, st);
+      rc = patch_analysis(residual, dictionary, Y, Cin, patches, g, pp, st);
       if (rc != VTC_OK) return rc;
     } else if (unit_path) {
       // stride-1 square kernels: scalar-tap kernels, the kernel sum of the
@@ -666,16 +683,21 @@ extern "C" int vtc_conv_ista_fista(
                              syn_groups, syn_per_group, st);
       if (rc != VTC_OK) return rc;
       rc = launch_analysis_unit(residual, images_padded, syn_groups,
-                                dictionary, Y, codes, g, pp, st);
+                                dictionary, Y, Cin, g, pp, st);
       if (rc != VTC_OK) return rc;
     } else {
       rc = launch_synthesis(Y, dictionary, images_padded, residual, g, st);
       if (rc != VTC_OK) return rc;
       hipLaunchKernelGGL(conv_analysis_prox_kernel,
                          dim3((unsigned)(tiles_p * tiles_q), (unsigned)g.b),
-                         dim3(256), ap.lds_bytes, st, residual, Kt, Y, codes,
+                         dim3(256), ap.lds_bytes, st, residual, Kt, Y, Cin,
                          g, ap.tp, ap.tq, ap.wy, ap.wx, tiles_q, pp);
       VTC_LAUNCH_CHECK();
+    }
+    if (!(x3 && synp_image)) {
+      // what was written becomes what is read
+      float* t = Cin; Cin = Cout; Cout = t;
+      if (fista) { t = Y; Y = Yout; Yout = t; }
     }
     done = k + 1;
     if (eps >= 0.f) {
@@ -687,6 +709,9 @@ extern "C" int vtc_conv_ista_fista(
       if (mean < eps && k > 0) break;
     }
   }
+  if (Cin != codes)
+    VTC_HIP_CHECK(hipMemcpyAsync(codes, Cin, code_bytes,
+                                 hipMemcpyDeviceToDevice, st));
   if (iters_run) *iters_run = done;
   return VTC_OK;
 }

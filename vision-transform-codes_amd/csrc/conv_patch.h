@@ -101,11 +101,11 @@ struct EpiPatchProx {
     float d;
     if (pp.fista) {
       d = sub_rn(c, C[idx]);
-      Y[idx] = add_rn(c, mul_rn(pp.beta, d));
+      pp.y_out[idx] = add_rn(c, mul_rn(pp.beta, d));
     } else {
       d = sub_rn(c, yv);
     }
-    C[idx] = c;
+    pp.c_out[idx] = c;
     if (pp.delta_sum) local += (double)(fabsf(d) / pp.eta);
   }
   __device__ __forceinline__ void block_end() const {

@@ -415,6 +415,11 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       (void*)(Y + img * g.s * map), 0, code_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(C + img * g.s * map), 0, code_bytes, 0x00020000);
+  // out of place (ProxParams): never the lines that are read
+  const __amdgpu_buffer_rsrc_t yws = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(pp.y_out + img * g.s * map), 0, code_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t cws = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(pp.c_out + img * g.s * map), 0, code_bytes, 0x00020000);
   const bool ragged = (g.s % AC) != 0;
   double local = 0.0;
   for (int pass = 0; pass < ana_rows / 4; ++pass) {
@@ -472,12 +477,12 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
         if (fista) {
           d = sub_rn(c, cv[r]);
           __builtin_amdgcn_raw_buffer_store_b32(
-              __float_as_uint(add_rn(c, mul_rn(pp.beta, d))), yrs, vo,
+              __float_as_uint(add_rn(c, mul_rn(pp.beta, d))), yws, vo,
               (unsigned)rr * map4, 0);
         } else {
           d = sub_rn(c, yv[r]);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), crs, vo,
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), cws, vo,
                                               (unsigned)rr * map4, 0);
         if (early && vo != 0x80000000u) local += (double)(fabsf(d) / pp.eta);
       }
