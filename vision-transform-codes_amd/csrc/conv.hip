@@ -558,8 +558,8 @@ extern "C" int vtc_conv_ista_fista(
   uint16_t* ana_image = nullptr;
   uint16_t* synp_image = nullptr;   // fused iteration kernel (conv_x3.h)
   float* partial = nullptr;
-  float* Ypad = nullptr;            // padded-row code maps of that kernel
-  float* Cpad = nullptr;
+  float* Cfrag1 = nullptr;          // the last two code iterates of that
+  float* Cfrag0 = nullptr;          // kernel, fragment order (CxMaps)
   if (x3) {
     syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
@@ -570,8 +570,8 @@ extern "C" int vtc_conv_ista_fista(
         threshold == VTC_SOFT && early_stopping_epsilon < 0.f && !no_fused) {
       synp_image = ws.take<uint16_t>(xp.synp_image_bytes / 2);
       partial = ws.take<float>(xp.partial_bytes / sizeof(float));
-      Ypad = ws.take<float>(xp.padded_bytes / sizeof(float));
-      Cpad = ws.take<float>(xp.padded_bytes / sizeof(float));
+      Cfrag1 = ws.take<float>(xp.padded_bytes / sizeof(float));
+      Cfrag0 = ws.take<float>(xp.padded_bytes / sizeof(float));
       hipLaunchKernelGGL(conv_x3_pack_synp_kernel, dim3(256), dim3(256), 0, st,
                          dictionary, synp_image, g.s, xp.k, xp.slots,
                          xp.chunks);
@@ -637,30 +637,31 @@ extern "C" int vtc_conv_ista_fista(
       // synthesis fused into the analysis epilogue: the residual of the first
       // iteration from the stand-alone synthesis (on the caller's layout),
       // the later ones from the partial tiles of the previous fused launch.
-      // Between the launches Y and the codes live in fragment order
-      // (conv_x3.h, CxMaps); the last launch writes the codes in the caller's
-      // layout.
+      // Between the launches the last two code iterates live in fragment
+      // order (conv_x3.h, CxMaps; Y is recomputed from them); the last launch
+      // writes the codes in the caller's layout.
       if (k == 0) {
         rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
                              st);
         if (rc != VTC_OK) return rc;
-        VTC_HIP_CHECK(hipMemsetAsync(Ypad, 0, xp.padded_bytes, st));
-        VTC_HIP_CHECK(hipMemsetAsync(Cpad, 0, xp.padded_bytes, st));
+        VTC_HIP_CHECK(hipMemsetAsync(Cfrag1, 0, xp.padded_bytes, st));
+        VTC_HIP_CHECK(hipMemsetAsync(Cfrag0, 0, xp.padded_bytes, st));
         if (initial_codes) {
           const int tu = (int)ceil_div(g.ch, 8), tv = (int)ceil_div(g.cw, 32);
           hipLaunchKernelGGL(conv_to_fragments_kernel, dim3(4096), dim3(256),
-                             0, st, initial_codes, Cpad, g, tu, tv, xp.chunks,
+                             0, st, initial_codes, Cfrag0, g, tu, tv, xp.chunks,
                              8, 32);
           VTC_LAUNCH_CHECK();
-          VTC_HIP_CHECK(hipMemcpyAsync(Ypad, Cpad, xp.padded_bytes,
+          VTC_HIP_CHECK(hipMemcpyAsync(Cfrag1, Cfrag0, xp.padded_bytes,
                                        hipMemcpyDeviceToDevice, st));
         }
       }
       const bool last = k + 1 == num_iters;
       CxMaps maps;
-      maps.Y = Ypad;
-      maps.C = Cpad;
+      maps.cur = (k & 1) ? Cfrag1 : Cfrag0;          // c_k
+      maps.old = (k & 1) ? Cfrag0 : Cfrag1;          // c_(k-1) in, c_(k+1) out
       maps.user_codes = last ? codes : nullptr;
+      maps.beta_prev = k > 0 ? betas[k - 1] : 0.f;
       rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
                            images_padded, residual, g, xp, pp, !last, st);
       if (rc != VTC_OK) return rc;

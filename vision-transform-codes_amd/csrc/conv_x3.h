@@ -669,10 +669,15 @@ struct CxItem {
 // updates -- a ~10 % chance per launch of a wrong 64-byte piece.)
 // The caller's (b, s, ch, cw) layout appears at the two ends only: initial
 // codes are converted once, the last launch writes its codes in that layout.
+// The momentum iterate Y is not stored at all: y_k = c_k + beta_(k-1) (c_k -
+// c_(k-1)) is recomputed, with the very operations that formed it, from the
+// last two code iterates -- three passes over the code maps per iteration
+// (read c_k, read c_(k-1), write c_(k+1) where c_(k-1) was) instead of four.
 struct CxMaps {
-  float* Y;            // momentum iterate, fragment order, updated in place
-  float* C;            // codes of the last iteration, fragment order
+  const float* cur;    // c_k, fragment order
+  float* old;          // c_(k-1) in, c_(k+1) out, fragment order
   float* user_codes;   // last launch: the caller's (b, s, ch, cw); else null
+  float beta_prev;     // beta_(k-1); 0 in the first iteration (y_0 = c_0)
 };
 
 // floats of one fragment-order set of code maps
@@ -767,15 +772,14 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
         const __bf16 h = (__bf16)wreg[q];
         const uint16_t hb = cx_bits(h);
         const uint16_t lb = cx_bits((__bf16)(wreg[q] - (float)h));
-        const int rx = e % WPITCH;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          // pixel x of a row sits at position x - c of copy c; the first c
-          // pixels of a row are never the start of a copy-c read
-          if (rx >= c) {
-            Wb[c * F::WIN_COPY + e - c] = hb;
-            Wb[c * F::WIN_COPY + F::WIN_ELEMS + e - c] = lb;
-          }
+          // pixel x of a row sits at position x - c of copy c.  The first c
+          // pixels of a row land on positions 45 .. 47 of the row before (or
+          // in the padding of the copy before): reads end at position 43,
+          // nothing there is ever used.
+          Wb[c * F::WIN_COPY + e - c] = hb;
+          Wb[c * F::WIN_COPY + F::WIN_ELEMS + e - c] = lb;
         }
       }
     }
@@ -800,10 +804,10 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   // fragment-order block of (item, this chunk, this wave's row, atom tile):
   // byte offset, wave-uniform (the scalar offset of the buffer accesses; the
   // lane part is lane * 16 for every access)
-  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)M.Y, 0, (int)frag_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)M.old, 0, (int)frag_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)M.C, 0, (int)frag_bytes, 0x00020000);
+      (void*)M.cur, 0, (int)frag_bytes, 0x00020000);
   const unsigned lane16 = (unsigned)lane * 16u;
   auto block_of = [&](const CxItem& it, int ma) -> unsigned {
     const int item_index =
@@ -818,7 +822,7 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
       const cx_u32x4 y4 = __builtin_amdgcn_raw_buffer_load_b128(
-          yrs, lane16 + 1024u * k4, blk, 0);
+          ors, lane16 + 1024u * k4, blk, 0);
       const cx_u32x4 c4 = __builtin_amdgcn_raw_buffer_load_b128(
           crs, lane16 + 1024u * k4, blk, 0);
 #pragma unroll
@@ -828,9 +832,10 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       }
     }
   };
-  // proximal step on atom tile ma of the current item, in registers: the new
-  // Y replaces the gradient in `tile` (zero where outside the problem, for the
-  // synthesis), the new codes replace the old ones in cv
+  // proximal step on atom tile ma of the current item, in registers (yv holds
+  // c_(k-1), cv holds c_k): the new Y replaces the gradient in `tile` (zero
+  // where outside the problem, for the synthesis), the new codes replace the
+  // old ones in cv
   auto prox_tile = [&](const CxItem& it, int ma, const float (&yv)[16],
                        float (&cv)[16], f32x16& tile) {
     const bool inside = it.v0 + l31 < g.cw;          // the row is (row_ok)
@@ -838,7 +843,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
-      const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
+      const float y = add_rn(cv[r], mul_rn(M.beta_prev, sub_rn(cv[r], yv[r])));
+      const float p = sub_rn(y, mul_rn(pp.eta, tile[r]));
       const float c = shrink(p, pp.cutoff, VTC_SOFT);
       const float d = sub_rn(c, cv[r]);
       const float y1 = add_rn(c, mul_rn(pp.beta, d));
@@ -875,15 +881,10 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     const unsigned blk = block_of(it, ma);
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
-      cx_u32x4 y4, c4;
+      cx_u32x4 c4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        y4[j] = __float_as_uint(tile[4 * k4 + j]);
-        c4[j] = __float_as_uint(cv[4 * k4 + j]);
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(y4, yrs, lane16 + 1024u * k4, blk,
-                                             0);
-      __builtin_amdgcn_raw_buffer_store_b128(c4, crs, lane16 + 1024u * k4, blk,
+      for (int j = 0; j < 4; ++j) c4[j] = __float_as_uint(cv[4 * k4 + j]);
+      __builtin_amdgcn_raw_buffer_store_b128(c4, ors, lane16 + 1024u * k4, blk,
                                              0);
     }
   };
