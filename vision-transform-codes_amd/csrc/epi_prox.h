@@ -28,6 +28,14 @@ struct EpiGroupProx {
   // the threshold is lam * eta, one f32 multiply as on the host
   const float* eta_dev = nullptr;
   float lam = 0.f;
+  // Where the new Y and the new codes go: other buffers than the ones read
+  // (the caller swaps them per iteration).  The state is in the caller's
+  // row-major layout; when a row is not a multiple of 128 bytes, tiles of
+  // blocks on different XCDs share cache lines, and a line that two XCDs both
+  // read and partly rewrite within one launch can lose one of the updates
+  // (their L2s are not coherent within a launch).
+  float* Yo = nullptr;
+  float* Co = nullptr;
   __device__ __forceinline__ void resolve() {
     if (eta_dev) {
       eta = *eta_dev;
@@ -37,7 +45,7 @@ struct EpiGroupProx {
   // rows of the block as buffer resources: a row past the batch is past the
   // end of the resource (reads give 0, writes are dropped)
   struct Ctx {
-    __amdgpu_buffer_rsrc_t yrs, crs;
+    __amdgpu_buffer_rsrc_t yrs, crs, yws, cws;
   };
   __device__ __forceinline__ Ctx begin(int64_t m0, int64_t rows) const {
     const int64_t left = rows - m0 < kX3BM ? rows - m0 : kX3BM;
@@ -47,6 +55,10 @@ struct EpiGroupProx {
                                                 0x00020000);
     ctx.crs = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ld), 0, bytes,
                                                 0x00020000);
+    ctx.yws = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((Yo ? Yo : Y) + m0 * ld), 0, bytes, 0x00020000);
+    ctx.cws = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((Co ? Co : C) + m0 * ld), 0, bytes, 0x00020000);
     return ctx;
   }
   // Global accesses are 16 bytes per lane: lane l owns row (l >> 3) + 8 q
@@ -148,9 +160,9 @@ struct EpiGroupProx {
         c4[i] = __float_as_uint(cn);
         if (delta_sum) local += (double)(fabsf(d) / eta);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yrs, off,
+      __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yws, off,
                                              (unsigned)(8 * q) * ld4, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(c4, ctx.crs, off,
+      __builtin_amdgcn_raw_buffer_store_b128(c4, ctx.cws, off,
                                              (unsigned)(8 * q) * ld4, 0);
     }
   }

@@ -33,6 +33,8 @@ struct EpiProx {
   double local;
   const float* eta_dev = nullptr;   // sync-free callers, see epi_prox.h
   float lam = 0.f;
+  float* Yo = nullptr;              // out-of-place targets, see epi_prox.h
+  float* Co = nullptr;
   __device__ __forceinline__ void resolve() {
     if (eta_dev) {
       eta = *eta_dev;
@@ -48,11 +50,11 @@ struct EpiProx {
     float d;
     if (fista) {
       d = sub_rn(c, C[i]);
-      Y[i] = add_rn(c, mul_rn(beta, d));
+      Yo[i] = add_rn(c, mul_rn(beta, d));
     } else {
       d = sub_rn(c, y);
     }
-    C[i] = c;
+    Co[i] = c;
     if (delta_sum) local += (double)(fabsf(d) / eta);
   }
   __device__ __forceinline__ void block_end() {
@@ -79,7 +81,7 @@ int launch_transpose(const float* in, float* out, int64_t rows, int64_t cols,
 
 static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
   size_t bytes = 0;
-  bytes += align_up((size_t)b * s * sizeof(float), 256);  // Y
+  bytes += 3 * align_up((size_t)b * s * sizeof(float), 256);  // Y, Y', C'
   bytes += align_up((size_t)b * n * sizeof(float), 256);  // R
   bytes += align_up((size_t)s * n * sizeof(float), 256);  // D^T (bf16x3)
   bytes += align_up((size_t)gemm_x3_want_slices(b, n, s) * b * n *
@@ -105,6 +107,8 @@ static int run_generic(const float* images, const float* dictionary,
   }
   Carver ws(workspace);
   float* Ybuf = ws.take<float>((size_t)b * s);
+  float* Yalt = ws.take<float>((size_t)b * s);   // out-of-place targets of the
+  float* Calt = ws.take<float>((size_t)b * s);   // proximal epilogue
   float* R = ws.take<float>((size_t)b * n);
   float* Dt = ws.take<float>((size_t)s * n);
   const int k1_slices = x3 ? gemm_x3_want_slices(b, n, s) : 1;
@@ -137,7 +141,11 @@ static int run_generic(const float* images, const float* dictionary,
   std::vector<float> betas;
   fista_betas(num_iters, &betas);
   int done = 0;
+  float* Cin = codes;      // (Y, Cin) are read, (Yout, Cout) written, then the
+  float* Cout = Calt;      // roles swap
+  float* Yout = Yalt;
   for (int k = 0; k < num_iters; ++k) {
+    if (!fista) Y = Cin;   // ISTA evaluates the gradient at the codes
     // R = Y D - X : A = Y (b,s) k-contiguous, B = D (s,n) = [K][N]
     EpiMinus e1{R, images, n, n};
     int rc;
@@ -162,21 +170,29 @@ static int run_generic(const float* images, const float* dictionary,
     if (x3 || wide_ok) {
       // 16-byte, pipelined epilogue (epi_prox.h); in ISTA Y and the codes are
       // one buffer and both stores carry the same value
-      EpiGroupProx<1, true> e2{Y, codes, s, eta, cutoff,
+      EpiGroupProx<1, true> e2{Y, Cin, s, eta, cutoff,
                                fista ? betas[k] : 0.f, fista ? 1 : 0,
                                eps >= 0.f ? delta_sum : nullptr, 0.0,
                                threshold, eta_dev, lam};
+      e2.Yo = fista ? Yout : Cout;
+      e2.Co = Cout;
       rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st)
               : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
                                             e2, st);
     } else {
-      EpiProx e2{Y, codes, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
+      EpiProx e2{Y, Cin, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
                  fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0,
                  eta_dev, lam};
+      e2.Yo = Yout;
+      e2.Co = Cout;
       rc = launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1, e2,
                                        st);
     }
     if (rc != VTC_OK) return rc;
+    {
+      float* t = Cin; Cin = Cout; Cout = t;
+      if (fista) { t = Y; Y = Yout; Yout = t; }
+    }
     done = k + 1;
     if (eps >= 0.f) {
       double total = 0.0;
@@ -187,6 +203,9 @@ static int run_generic(const float* images, const float* dictionary,
       if (mean < eps && k > 0) break;  // ista_fista.py:143-144
     }
   }
+  if (Cin != codes)
+    VTC_HIP_CHECK(hipMemcpyAsync(codes, Cin, code_bytes,
+                                 hipMemcpyDeviceToDevice, st));
   if (iters_run) *iters_run = done;
   return VTC_OK;
 }

@@ -24,14 +24,15 @@
 
 namespace vtc {
 
-struct EpiGradStep {  // Y <- Y - eta * g
-  float* Y;
+struct EpiGradStep {  // Yo <- Y - eta * g  (out of place, see epi_prox.h)
+  const float* Y;
+  float* Yo;
   int64_t ld;
   float eta;
   __device__ __forceinline__ void operator()(int64_t row, int64_t col, float g,
                                              int) const {
     const int64_t i = row * ld + col;
-    Y[i] = sub_rn(Y[i], mul_rn(eta, g));
+    Yo[i] = sub_rn(Y[i], mul_rn(eta, g));
   }
   __device__ __forceinline__ void block_end() const {}
 };
@@ -40,10 +41,13 @@ struct EpiGradStep {  // Y <- Y - eta * g
 // epilogue, on the bf16x3 tiles or the exact-f32 ones
 template <int M>
 static int launch_grad_prox(bool x3, const float* R, const float* Dg, float* Y,
-                            float* C, int64_t b, int64_t slots, int64_t n,
-                            float eta, float cutoff, float beta, int fista,
-                            double* delta_sum, hipStream_t st) {
+                            float* C, float* Yo, float* Co, int64_t b,
+                            int64_t slots, int64_t n, float eta, float cutoff,
+                            float beta, int fista, double* delta_sum,
+                            hipStream_t st) {
   EpiGroupProx<M> e{Y, C, slots, eta, cutoff, beta, fista, delta_sum, 0.0, 0};
+  e.Yo = Yo;
+  e.Co = Co;
   return x3 ? launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st)
             : launch_gemm_f32<true, true>(R, n, Dg, n, b, slots, n, 1, e, st);
 }
@@ -225,7 +229,7 @@ static bool launch_group_prox_pow2(float* Y, float* C, int64_t b,
 }
 
 static size_t subspace_ws_bytes(int64_t b, int64_t n, int64_t slots) {
-  return align_up((size_t)b * slots * sizeof(float), 256) +   // Y
+  return 3 * align_up((size_t)b * slots * sizeof(float), 256) +  // Y, Y', C'
          align_up((size_t)b * n * sizeof(float), 256) +       // R
          align_up((size_t)slots * n * sizeof(float), 256) +   // Dg^T (bf16x3)
          align_up((size_t)gemm_x3_want_slices(b, n, slots) * b * n *
@@ -367,6 +371,9 @@ extern "C" int vtc_subspace_ista_fista(
   hipStream_t st = as_stream(stream);
   Carver ws(workspace);
   float* Y = ws.take<float>((size_t)b * slots);
+  float* Yout = ws.take<float>((size_t)b * slots);  // out-of-place targets of
+  float* Cout = ws.take<float>((size_t)b * slots);  // the proximal epilogue
+  float* Cin = grouped_codes;
   float* R = ws.take<float>((size_t)b * n);
   float* DgT = ws.take<float>((size_t)slots * n);
   const int k1_slices = (precision == VTC_BF16X3)
@@ -433,8 +440,8 @@ extern "C" int vtc_subspace_ista_fista(
     if (wide_ok) {
 #define VTC_FUSED_PROX(MM)                                                  \
   case MM:                                                                  \
-    rc = launch_grad_prox<MM>(x3, R, grouped_dictionary, Y, grouped_codes,  \
-                                 b, slots, n, eta, cutoff, beta_k,          \
+    rc = launch_grad_prox<MM>(x3, R, grouped_dictionary, Y, Cin, Yout,     \
+                                 Cout, b, slots, n, eta, cutoff, beta_k,    \
                                  fista ? 1 : 0, dsum, st);                  \
     fused_prox = true;                                                      \
     break;
@@ -450,19 +457,24 @@ extern "C" int vtc_subspace_ista_fista(
 #undef VTC_FUSED_PROX
       if (fused_prox) {
         if (rc != VTC_OK) return rc;
+        float* t = Cin; Cin = Cout; Cout = t;
+        t = Y; Y = Yout; Yout = t;
       }
     }
     if (!fused_prox) {
-    EpiGradStep e2{Y, slots, eta};
+    // gradient step out of place, then the proximal kernels in place on the
+    // new buffer (their blocks own whole, 128-byte aligned runs of rows)
+    EpiGradStep e2{Y, Yout, slots, eta};
     rc = x3 ? launch_gemm_x3(R, n, grouped_dictionary, n, b, slots, n, e2, st)
             : launch_gemm_f32<true, true>(R, n, grouped_dictionary, n, b,
                                           slots, n, 1, e2, st);
     if (rc != VTC_OK) return rc;
-    if (!launch_group_prox_pow2(Y, grouped_codes, b, groups, (int)m, cutoff,
+    { float* t = Y; Y = Yout; Yout = t; }
+    if (!launch_group_prox_pow2(Y, Cin, b, groups, (int)m, cutoff,
                                 fista ? betas[k] : 0.f, fista ? 1 : 0, eta,
                                 eps >= 0.f ? delta_sum : nullptr, st))
       hipLaunchKernelGGL(group_prox_kernel, dim3(flat_grid(b * groups)),
-                         dim3(256), 0, st, Y, grouped_codes, b, groups, (int)m,
+                         dim3(256), 0, st, Y, Cin, b, groups, (int)m,
                          cutoff, fista ? betas[k] : 0.f, fista ? 1 : 0, eta,
                          eps >= 0.f ? delta_sum : nullptr);
     VTC_LAUNCH_CHECK();
@@ -478,6 +490,9 @@ extern "C" int vtc_subspace_ista_fista(
       if (mean < eps && k > 0) break;
     }
   }
+  if (Cin != grouped_codes)
+    VTC_HIP_CHECK(hipMemcpyAsync(grouped_codes, Cin, bytes,
+                                 hipMemcpyDeviceToDevice, st));
   if (iters_run) *iters_run = done;
   return VTC_OK;
 }
