@@ -18,14 +18,16 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, int iters) {
   if (MODE == 0) off = lane * 8;                          // aligned, contiguous
   else if (MODE == 1) off = l31 + 8 * half;               // conv pattern, 2-byte aligned
   else if (MODE == 2) off = (l31 + 8 * half) & ~7;        // same addresses rounded to 16 B
-  else off = (l31 + 8 * half) & ~3;                       // 8-byte aligned
+  else if (MODE == 3) off = (l31 + 8 * half) & ~3;        // 8-byte aligned
+  else if (MODE == 4) off = l31 * 16 + 8 * half;          // 32-byte lane stride, halves interleaved
+  else off = l31 * 72 + 8 * half;                         // 144-byte lane stride (synthesis operand rows)
   unsigned acc = 0;
   unsigned long long t0, t1;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = off + ((it * 16 + r) & 63) * 48;
+      const int o = off + ((it * 16 + r) & 63) * (MODE >= 4 ? 64 : 48);
       if (MODE == 3) {
         const uint2 a = *reinterpret_cast<const uint2*>(buf + o);
         const uint2 b = *reinterpret_cast<const uint2*>(buf + o + 4);
@@ -45,9 +47,11 @@ int main() {
   unsigned long long* d;
   hipMalloc(&d, 16);
   const int iters = 2000;
-  const char* names[4] = {"aligned b128, contiguous", "2-byte aligned b128 (conv window)",
-                          "same, rounded to 16 B", "8-byte aligned, 2 x b64"};
-  for (int mode = 0; mode < 4; ++mode) {
+  const char* names[6] = {"aligned b128, contiguous", "2-byte aligned b128 (conv window)",
+                          "same, rounded to 16 B", "8-byte aligned, 2 x b64",
+                          "b128, lane stride 32 B (l31), +16 B (half)",
+                          "b128, lane stride 144 B (l31), +16 B (half)"};
+  for (int mode = 0; mode < 6; ++mode) {
     for (int waves = 1; waves <= 8; waves *= 2) {
       hipMemset(d, 0, 16);
       const dim3 grid(256), block(64 * waves);
@@ -55,6 +59,8 @@ int main() {
       if (mode == 1) hipLaunchKernelGGL(k<1>, grid, block, 0, 0, d, iters);
       if (mode == 2) hipLaunchKernelGGL(k<2>, grid, block, 0, 0, d, iters);
       if (mode == 3) hipLaunchKernelGGL(k<3>, grid, block, 0, 0, d, iters);
+      if (mode == 4) hipLaunchKernelGGL(k<4>, grid, block, 0, 0, d, iters);
+      if (mode == 5) hipLaunchKernelGGL(k<5>, grid, block, 0, 0, d, iters);
       unsigned long long h = 0;
       hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
       const double per_wave = (double)h / (256.0 * waves);

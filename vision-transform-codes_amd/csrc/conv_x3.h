@@ -79,7 +79,7 @@ __device__ __forceinline__ uint16_t cx_bits(__bf16 v) {
 
 // ------------------------------------------------------------------ pack
 // syn image (uint16): [plane][slot][s16 + 8]      D[s][tap(slot)], k = s
-// ana image (uint16): [chunk][plane][dy][AC][16]  D[chunk*AC + a][dy][dx]
+// ana image (uint16): [chunk][plane][dy][2][AC][8]  D[chunk*AC + a][dy][8 h + j]
 __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
                                     uint16_t* __restrict__ syn,
                                     uint16_t* __restrict__ ana, int s, int k,
@@ -104,8 +104,12 @@ __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
       const int64_t f = e - syn_plane;
       const int chunk = (int)(f / ana_plane);
       const int rem = (int)(f % ana_plane);
-      const int dy = rem / (AC * 16), a = chunk * AC + (rem / 16) % AC,
-                dx = rem % 16;
+      // [dy][half][atom][8]: the two half-waves of an operand read (taps
+      // 0..7 / 8..15 of a tap row) each take 16 contiguous bytes per lane
+      // (atoms 32 bytes apart cost 1.75x the LDS cycles: r02_lds_unaligned.txt)
+      const int dy = rem / (AC * 16), within = rem % (AC * 16);
+      const int a = chunk * AC + (within / 8) % AC,
+                dx = 8 * (within / (AC * 8)) + within % 8;
       if (a < s && dx < k) v = D[(int64_t)a * taps + dy * k + dx];
       hi = ana + (int64_t)chunk * 2 * ana_plane + rem;
       lo = hi + ana_plane;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       }
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma) {
-        const int off = ((dy * AC + 32 * ma + l31) * 16) + 8 * half;
+        const int off = ((dy * 2 + half) * AC + 32 * ma + l31) * 8;
         const cx_bf16x8 ah = __builtin_bit_cast(
             cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
         const cx_bf16x8 al = __builtin_bit_cast(
@@ -979,11 +983,11 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     const uint2 l1 = *reinterpret_cast<const uint2*>(bp + F::WIN_ELEMS + 4);
     o.bh = make_uint4(h0.x, h0.y, h1.x, h1.y);
     o.bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    const int off = (dy * AC + l31) * 16 + 8 * half;
+    const int off = ((dy * 2 + half) * AC + l31) * 8;
     o.ah0 = *reinterpret_cast<const uint4*>(Dh + off);
     o.al0 = *reinterpret_cast<const uint4*>(Dl + off);
-    o.ah1 = *reinterpret_cast<const uint4*>(Dh + off + 32 * 16);
-    o.al1 = *reinterpret_cast<const uint4*>(Dl + off + 32 * 16);
+    o.ah1 = *reinterpret_cast<const uint4*>(Dh + off + 32 * 8);
+    o.al1 = *reinterpret_cast<const uint4*>(Dl + off + 32 * 8);
     return o;
   };
 
