@@ -27,6 +27,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include "gemm_f32.h"
 #include "fc_fused.h"
 
@@ -564,10 +565,9 @@ extern "C" int vtc_conv_ista_fista(
     syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
     rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
-    // fused iteration kernel: FISTA, soft threshold, no early stopping
+    // fused iteration kernel (kernels up to 11x11, more than 32 of them)
     static const bool no_fused = getenv("VTC_CONV_NO_FUSED") != nullptr;
-    if (rc == VTC_OK && xp.fused_lds != 0 && variant == VTC_FISTA &&
-        threshold == VTC_SOFT && early_stopping_epsilon < 0.f && !no_fused) {
+    if (rc == VTC_OK && xp.fused_lds != 0 && !no_fused) {
       synp_image = ws.take<uint16_t>(xp.synp_image_bytes / 2);
       partial = ws.take<float>(xp.partial_bytes / sizeof(float));
       Cfrag1 = ws.take<float>(xp.padded_bytes / sizeof(float));
@@ -626,6 +626,7 @@ extern "C" int vtc_conv_ista_fista(
   float* Cin = codes;
   float* Cout = Calt;
   float* Yout = Yalt;
+  const float* frag_latest = nullptr;   // fused path: newest codes (fragments)
   for (int k = 0; k < num_iters; ++k) {
     if (eps >= 0.f)
       VTC_HIP_CHECK(hipMemsetAsync(delta_sum, 0, sizeof(double), st));
@@ -656,15 +657,19 @@ extern "C" int vtc_conv_ista_fista(
                                        hipMemcpyDeviceToDevice, st));
         }
       }
-      const bool last = k + 1 == num_iters;
+      // with early stopping the last launch is not known in advance: the
+      // codes are converted when the loop ends
+      const bool last = k + 1 == num_iters && eps < 0.f;
       CxMaps maps;
       maps.cur = (k & 1) ? Cfrag1 : Cfrag0;          // c_k
       maps.old = (k & 1) ? Cfrag0 : Cfrag1;          // c_(k-1) in, c_(k+1) out
       maps.user_codes = last ? codes : nullptr;
-      maps.beta_prev = k > 0 ? betas[k - 1] : 0.f;
+      maps.beta_prev = (fista && k > 0) ? betas[k - 1] : 0.f;
       rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
-                           images_padded, residual, g, xp, pp, !last, st);
+                           images_padded, residual, g, xp, pp,
+                           k + 1 < num_iters, st);
       if (rc != VTC_OK) return rc;
+      frag_latest = maps.old;
     } else if (x3) {
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
       if (rc != VTC_OK) return rc;
@@ -710,9 +715,15 @@ extern "C" int vtc_conv_ista_fista(
       if (mean < eps && k > 0) break;
     }
   }
-  if (Cin != codes)
+  if (x3 && synp_image && eps >= 0.f) {
+    const int tu = (int)ceil_div(g.ch, 8), tv = (int)ceil_div(g.cw, 32);
+    hipLaunchKernelGGL(conv_from_fragments_kernel, dim3(4096), dim3(256), 0,
+                       st, frag_latest, codes, g, tu, tv, xp.chunks, 8, 32);
+    VTC_LAUNCH_CHECK();
+  } else if (Cin != codes) {
     VTC_HIP_CHECK(hipMemcpyAsync(codes, Cin, code_bytes,
                                  hipMemcpyDeviceToDevice, st));
+  }
   if (iters_run) *iters_run = done;
   return VTC_OK;
 }

@@ -840,8 +840,12 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   // c_(k-1), cv holds c_k): the new Y replaces the gradient in `tile` (zero
   // where outside the problem, for the synthesis), the new codes replace the
   // old ones in cv
-  auto prox_tile = [&](const CxItem& it, int ma, const float (&yv)[16],
-                       float (&cv)[16], f32x16& tile) {
+  // early stopping only: sum of |c' - c| / eta of the item (added to the
+  // global sum per item, so that nothing is carried through the item loop)
+  float stop_sum = 0.f;
+  auto prox_mode = [&](auto mode_tag, const CxItem& it, int ma,
+                       const float (&yv)[16], float (&cv)[16], f32x16& tile) {
+    constexpr int MODE = decltype(mode_tag)::value;
     const bool inside = it.v0 + l31 < g.cw;          // the row is (row_ok)
     const int left = g.s - (chunk * AC + 32 * ma + 4 * half);
 #pragma unroll
@@ -849,12 +853,34 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       const int rr = (r & 3) + 8 * (r >> 2);
       const float y = add_rn(cv[r], mul_rn(M.beta_prev, sub_rn(cv[r], yv[r])));
       const float p = sub_rn(y, mul_rn(pp.eta, tile[r]));
-      const float c = shrink(p, pp.cutoff, VTC_SOFT);
+      const float c = shrink(p, pp.cutoff, MODE);
       const float d = sub_rn(c, cv[r]);
       const float y1 = add_rn(c, mul_rn(pp.beta, d));
       const bool ok = inside && (!RAGGED || rr < left);
+      if (pp.delta_sum && ok) stop_sum += fabsf(d) / pp.eta;
       cv[r] = ok ? c : 0.f;
       tile[r] = ok ? y1 : 0.f;
+    }
+  };
+  // (ISTA is the same recursion with every beta = 0; the threshold is one of
+  // four compile-time variants behind a uniform branch)
+  auto prox_tile = [&](const CxItem& it, int ma, const float (&yv)[16],
+                       float (&cv)[16], f32x16& tile) {
+    switch (pp.mode) {
+      case VTC_SOFT:
+        prox_mode(std::integral_constant<int, VTC_SOFT>{}, it, ma, yv, cv, tile);
+        break;
+      case VTC_SOFT_NONNEG:
+        prox_mode(std::integral_constant<int, VTC_SOFT_NONNEG>{}, it, ma, yv,
+                  cv, tile);
+        break;
+      case VTC_HARD:
+        prox_mode(std::integral_constant<int, VTC_HARD>{}, it, ma, yv, cv, tile);
+        break;
+      default:
+        prox_mode(std::integral_constant<int, VTC_HARD_NONNEG>{}, it, ma, yv,
+                  cv, tile);
+        break;
     }
   };
   auto store_tile = [&](const CxItem& it, int ma, const f32x16& tile,
@@ -1050,6 +1076,11 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       prox_tile(cur, 0, yA, cA, acc[0]);
       if (do_synth) synth_tile(0, acc[0]);
       prox_tile(cur, 1, yB, cB, acc[1]);
+      if (pp.delta_sum) {
+        const double w = wave_sum((double)stop_sum);
+        if (lane == 0) atomicAdd(pp.delta_sum, w);
+        stop_sum = 0.f;
+      }
       stamp(2);
       store_tile(cur, 0, acc[0], cA);
       store_tile(cur, 1, acc[1], cB);
@@ -1126,6 +1157,35 @@ __global__ void conv_to_fragments_kernel(const float* __restrict__ src,
     if (a0 + 2 < g.s) out.z = p[2 * map];
     if (a0 + 3 < g.s) out.w = p[3 * map];
     reinterpret_cast<float4*>(dst)[i] = out;
+  }
+}
+
+// fragment order -> (b, s, ch, cw)
+__global__ void conv_from_fragments_kernel(const float* __restrict__ src,
+                                           float* __restrict__ dst, ConvGeo g,
+                                           int tiles_u, int tiles_v,
+                                           int chunks, int rows, int cols) {
+  const int64_t total = (int64_t)g.b * tiles_u * tiles_v * chunks * rows * 2 * 256;
+  const int64_t map = (int64_t)g.ch * g.cw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63), k4 = (int)((i >> 6) & 3);
+    int64_t rest = i >> 8;
+    const int ma = (int)(rest & 1); rest >>= 1;
+    const int row = (int)(rest % rows); rest /= rows;
+    const int chunk = (int)(rest % chunks); rest /= chunks;
+    const int tv = (int)(rest % tiles_v); rest /= tiles_v;
+    const int tu = (int)(rest % tiles_u);
+    const int64_t img = rest / tiles_u;
+    const int u = tu * rows + row, v = tv * cols + (lane & 31);
+    if (u >= g.ch || v >= g.cw) continue;
+    const int a0 = chunk * 64 + 32 * ma + 8 * k4 + 4 * (lane >> 5);
+    const float4 in = reinterpret_cast<const float4*>(src)[i];
+    float* p = dst + (img * g.s + a0) * map + (int64_t)u * g.cw + v;
+    if (a0 + 0 < g.s) p[0] = in.x;
+    if (a0 + 1 < g.s) p[map] = in.y;
+    if (a0 + 2 < g.s) p[2 * map] = in.z;
+    if (a0 + 3 < g.s) p[3 * map] = in.w;
   }
 }
 
