@@ -816,8 +816,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   auto block_of = [&](const CxItem& it, int ma) -> unsigned {
     const int item_index =
         (it.img * tiles_u + it.u0 / F::ROWS) * tiles_v + it.v0 / F::COLS;
-    return (unsigned)((((item_index * chunks + chunk) * F::ROWS + wave) * 2 +
-                       ma) * 4096);
+    return ((((unsigned)item_index * (unsigned)chunks + (unsigned)chunk) *
+                 F::ROWS + (unsigned)wave) * 2u + (unsigned)ma) * 4096u;
   };
   auto load_tile = [&](const CxItem& it, int ma, float (&yv)[16],
                        float (&cv)[16]) {
@@ -851,11 +851,16 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rr = (r & 3) + 8 * (r >> 2);
-      const float y = add_rn(cv[r], mul_rn(M.beta_prev, sub_rn(cv[r], yv[r])));
+      // beta = 0 (ISTA, the first iterations) takes the iterate itself, as
+      // the reference does: 0 * (inf - inf) would turn a diverged entry to NaN
+      const float y = M.beta_prev != 0.f
+                          ? add_rn(cv[r], mul_rn(M.beta_prev,
+                                                 sub_rn(cv[r], yv[r])))
+                          : cv[r];
       const float p = sub_rn(y, mul_rn(pp.eta, tile[r]));
       const float c = shrink(p, pp.cutoff, MODE);
       const float d = sub_rn(c, cv[r]);
-      const float y1 = add_rn(c, mul_rn(pp.beta, d));
+      const float y1 = pp.beta != 0.f ? add_rn(c, mul_rn(pp.beta, d)) : c;
       const bool ok = inside && (!RAGGED || rr < left);
       if (pp.delta_sum && ok) stop_sum += fabsf(d) / pp.eta;
       cv[r] = ok ? c : 0.f;
@@ -1434,6 +1439,12 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
                        ceil_div(g.cw, F::COLS) * F::TILE_STRIDE * sizeof(float);
     p->padded_bytes =
         cx_frag_floats(g, p->chunks, F::ROWS, F::COLS) * sizeof(float);
+    // 32-bit byte offsets into the fragment-order maps and the partial tiles
+    if (p->padded_bytes >= ((size_t)1 << 32) ||
+        p->partial_bytes >= ((size_t)1 << 32)) {
+      p->fused_lds = 0;
+      p->synp_image_bytes = p->partial_bytes = p->padded_bytes = 0;
+    }
   }
 }
 
