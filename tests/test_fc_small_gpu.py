@@ -1,0 +1,75 @@
+"""The on-chip kernel for 8x8 patches (csrc/fc_small.hip: n = 64, 64 / 128 /
+192 atoms, exact f32 on the f32 matrix pipe) against the CPU oracle: ISTA and
+FISTA, the four thresholds, warm start, batches that are not multiples of a
+wave's 32 patches, the engine's own step size from device memory.  Tolerance
+of the exact-f32 path: 1e-5 relative on the codes, support identical above
+2e-6."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+import sc_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, b, s):
+  rs = np.random.RandomState(seed)
+  X = (0.1 * rs.randn(b, 64)).astype(np.float32)
+  D = rs.randn(s, 64).astype(np.float32)
+  D /= np.linalg.norm(D.astype(np.float64), axis=1, keepdims=True).astype(
+      np.float32)
+  return X, D
+
+
+def test_policy_routes_8x8_patches_to_the_on_chip_kernel(device):
+  import vtc_hip
+  from analysis_transforms.fully_connected import ista_fista
+  for s in (64, 128, 192):
+    assert ista_fista._resolve_precision(None, 1 << 17, 64, s, None) == (
+        vtc_hip.F32)
+  lib = vtc_hip.load_library()
+  # no workspace beyond the tiled path's is asked for; the shape is accepted
+  assert lib.vtc_fc_ista_fista_workspace_bytes(1000, 64, 64, vtc_hip.F32) > 0
+
+
+@pytest.mark.parametrize('s', [64, 128, 192])
+@pytest.mark.parametrize('b', [1, 31, 32, 33, 1000])
+def test_against_the_oracle(device, s, b):
+  from analysis_transforms.fully_connected import ista_fista
+  X, D = _case(100 * s + b, b, s)
+  Xd, Dd = helpers.to_dev(X, device), helpers.to_dev(D, device)
+  eta = float(sc_oracle.fc_stepsize(torch.from_numpy(D)))
+  for kw in ({'variant': 'fista'}, {'variant': 'ista'},
+             {'variant': 'fista', 'nonnegative_only': True},
+             {'variant': 'ista', 'hard_threshold': True},
+             {'variant': 'fista', 'hard_threshold': True,
+              'nonnegative_only': True}):
+    # a hard threshold is discontinuous: few iterations, flips at the cutoff
+    iters = 3 if kw.get('hard_threshold') else 40
+    ref = sc_oracle.fc_ista_fista(torch.from_numpy(X), torch.from_numpy(D),
+                                  0.02, iters, stepsize=eta, **kw)
+    out = ista_fista.run(Xd, Dd, 0.02, iters, stepsize=eta, precision='f32',
+                         **kw)
+    flip = 0.02 * eta * 1.01 if kw.get('hard_threshold') else 2e-6
+    helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                               's=%d b=%d %r' % (s, b, kw), max_flip_mag=flip)
+
+
+def test_warm_start_own_stepsize_and_reproducibility(device):
+  from analysis_transforms.fully_connected import ista_fista
+  X, D = _case(5, 777, 128)
+  Xd, Dd = helpers.to_dev(X, device), helpers.to_dev(D, device)
+  warm = sc_oracle.fc_ista_fista(torch.from_numpy(X), torch.from_numpy(D),
+                                 0.02, 5)
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(X), torch.from_numpy(D),
+                                0.02, 30, initial_codes=warm)
+  # default precision, default (device-side) step size
+  a = ista_fista.run(Xd, Dd, 0.02, 30,
+                     initial_codes=helpers.to_dev(warm.numpy(), device))
+  b = ista_fista.run(Xd, Dd, 0.02, 30,
+                     initial_codes=helpers.to_dev(warm.numpy(), device))
+  helpers.assert_codes_match(a.cpu().numpy(), ref.numpy(), 1e-5,
+                             'warm start, own eta', max_flip_mag=2e-6)
+  assert torch.equal(a, b)

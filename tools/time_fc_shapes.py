@@ -22,6 +22,8 @@ NAMES = {vtc_hip.F32: 'f32 tiles', vtc_hip.BF16X3: 'bf16x3', vtc_hip.F16X3: 'f16
 print('%-34s %-10s %-34s %9s %9s' % ('shape', 'variant', 'path taken by precision=auto',
                                        'ms', 'TFLOP/s'))
 for n, s, b, iters, variant in ((64, 64, 131072, 20, 'ista'),
+                                (64, 128, 131072, 50, 'fista'),
+                                (64, 192, 131072, 50, 'fista'),
                                 (64, 256, 131072, 50, 'fista'),
                                 (144, 576, 32768, 50, 'fista'),
                                 (400, 1600, 16384, 50, 'fista'),
@@ -39,6 +41,8 @@ for n, s, b, iters, variant in ((64, 64, 131072, 20, 'ista'),
     path = 'fused kernel, ' + NAMES[prec]
   elif n == 256 and s > 1024 and s % 256 == 0 and prec != vtc_hip.F32:
     path = 'fused, streamed state, ' + NAMES[prec]
+  elif n == 64 and s in (64, 128, 192) and prec == vtc_hip.F32:
+    path = 'on-chip 8x8 kernel, exact f32'
   else:
     path = 'tiled contractions, ' + NAMES[prec]
   best = 1e9

@@ -124,6 +124,12 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
                    s > 1024 and s % 256 == 0 and fused_available())
     if fused_ok or streamed_ok:
       return vtc_hip.F16X3
+    # 8x8 patches against 64 / 128 / 192 atoms: the exact-f32 on-chip kernel
+    # (csrc/fc_small.hip) beats the split-bf16 tiles, which are HBM-bound there
+    small_ok = (early_stopping_epsilon is None and n == 64 and
+                s in (64, 128, 192))
+    if small_ok:
+      return vtc_hip.F32
     return vtc_hip.BF16X3 if tiled_ok else vtc_hip.F32
   return vtc_hip.PRECISIONS[name]
 

@@ -16,6 +16,7 @@
 #include "epi_prox.h"
 #include "fc_fused.h"
 #include "fused_stream.h"
+#include "fc_small.h"
 
 #include <math.h>
 #include <vector>
@@ -266,6 +267,12 @@ static int fc_ista_fista_impl(const float* images, const float* dictionary,
               "VTC_F16X3, VTC_BF16X3 or VTC_F32");
     return VTC_ERR_UNSUPPORTED;
   }
+  // 8x8 patches against 64 / 128 atoms, exact f32: everything on the CU
+  if (precision == VTC_F32 && early_stopping_epsilon < 0.f &&
+      num_iters <= fused_max_iters() && small_shape_supported(n, s))
+    return run_small(images, dictionary, initial_codes, codes, b, n, s,
+                     stepsize, stepsize_dev, sparsity_weight, num_iters,
+                     variant, threshold, iters_run, st);
   if (precision != VTC_F32 && fused_ok)
     return run_fused(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
