@@ -115,7 +115,14 @@ size_t vtc_fc_ista_fista_workspace_bytes(int64_t b, int64_t n, int64_t s,
 /* images (b,n), dictionary (s,n), initial_codes (b,s) or NULL, codes (b,s) out.
  * stepsize = eta = 1/L.  The threshold is float(sparsity_weight)*eta in f32.
  * early_stopping_epsilon < 0 disables the stopping test (sync-free).
- * iters_run (host int*, may be NULL) receives the iterations executed. */
+ * iters_run (host int*, may be NULL) receives the iterations executed.
+ * Kernels behind it: 16x16 patches (n = 256) with 256 / 512 / 1024 atoms take
+ * the fused persistent kernel in the split precisions, more atoms (multiples
+ * of 256) the fused kernel with streamed state; 8x8 patches (n = 64) with 64 /
+ * 128 / 192 atoms take an on-chip exact-f32 kernel under VTC_F32; every other
+ * shape, and early stopping, the tiled contractions with the proximal step in
+ * their epilogue.  `codes` is only ever written, never read-modified in
+ * place. */
 int vtc_fc_ista_fista(const float* images, const float* dictionary,
                       const float* initial_codes, float* codes, int64_t b,
                       int64_t n, int64_t s, float stepsize,
@@ -187,7 +194,10 @@ int vtc_conv_x3_supported(const vtc_conv_geometry* g);
 /* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w).
  * precision: VTC_F32 (direct f32 convolutions, fixed summation order) or
  * VTC_BF16X3 (both convolutions as bf16 hi/lo split MFMA contractions;
- * VTC_ERR_UNSUPPORTED unless vtc_conv_x3_supported). */
+ * VTC_ERR_UNSUPPORTED unless vtc_conv_x3_supported).  With kernels up to
+ * 11x11 and more than 32 of them VTC_BF16X3 runs one fused launch per
+ * iteration (analysis, proximal step and the next residual) on code maps kept
+ * in an internal tile order; the caller's layout is written by the last one. */
 int vtc_conv_ista_fista(const float* images_padded, const float* dictionary,
                         const float* initial_codes, float* codes,
                         const vtc_conv_geometry* g, float stepsize,
