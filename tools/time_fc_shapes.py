@@ -25,6 +25,7 @@ for n, s, b, iters, variant in ((64, 64, 131072, 20, 'ista'),
                                 (64, 128, 131072, 50, 'fista'),
                                 (64, 192, 131072, 50, 'fista'),
                                 (64, 256, 131072, 50, 'fista'),
+                                (64, 512, 65536, 50, 'fista'),
                                 (144, 576, 32768, 50, 'fista'),
                                 (400, 1600, 16384, 50, 'fista'),
                                 (256, 1024, 131072, 200, 'fista'),
@@ -41,6 +42,9 @@ for n, s, b, iters, variant in ((64, 64, 131072, 20, 'ista'),
     path = 'fused kernel, ' + NAMES[prec]
   elif n == 256 and s > 1024 and s % 256 == 0 and prec != vtc_hip.F32:
     path = 'fused, streamed state, ' + NAMES[prec]
+  elif ((n == 144 and s in (288, 576)) or (n == 64 and s in (256, 512))) and (
+      prec == vtc_hip.F32):
+    path = 'registers + L2 stream, exact f32'
   elif n == 64 and s in (64, 128, 192) and prec == vtc_hip.F32:
     path = 'on-chip 8x8 kernel, exact f32'
   else:

@@ -130,6 +130,11 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
                 s in (64, 128, 192))
     if small_ok:
       return vtc_hip.F32
+    # 12x12 patches against 288 / 576 atoms, 8x8 against 256 / 512: exact-f32
+    # kernel with the state in registers (csrc/fc_chip16.hip)
+    if early_stopping_epsilon is None and (
+        (n == 144 and s in (288, 576)) or (n == 64 and s in (256, 512))):
+      return vtc_hip.F32
     return vtc_hip.BF16X3 if tiled_ok else vtc_hip.F32
   return vtc_hip.PRECISIONS[name]
 

@@ -273,6 +273,13 @@ static int fc_ista_fista_impl(const float* images, const float* dictionary,
     return run_small(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
                      variant, threshold, iters_run, st);
+  // 12x12 patches against 288 / 576 atoms, exact f32: state on the CU
+  if (precision == VTC_F32 && early_stopping_epsilon < 0.f &&
+      num_iters <= fused_max_iters() && chip16_shape_supported(n, s))
+    return run_chip16(images, dictionary, initial_codes, codes, b, n, s,
+                      stepsize, stepsize_dev, sparsity_weight, num_iters,
+                      variant, threshold, workspace, workspace_bytes,
+                      iters_run, st);
   if (precision != VTC_F32 && fused_ok)
     return run_fused(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
