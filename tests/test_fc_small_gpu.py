@@ -110,3 +110,22 @@ def test_register_resident_kernel_against_the_oracle(device, n, s, b):
   helpers.assert_codes_match(a.cpu().numpy(), ref.numpy(), 1e-5,
                              '12x12 warm start', max_flip_mag=2e-6)
   assert torch.equal(a, b2)
+
+
+def test_misaligned_views_fall_back_to_the_tiled_path(device):
+  """The register-resident kernels move patches and codes as float4; a view
+  that starts 4 bytes into its storage takes the tiled path instead (and gives
+  the same codes within the f32 tolerance)."""
+  from analysis_transforms.fully_connected import ista_fista
+  X, D = _case(11, 100, 64)
+  eta = float(sc_oracle.fc_stepsize(torch.from_numpy(D)))
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(X), torch.from_numpy(D),
+                                0.02, 20, stepsize=eta)
+  flat = torch.zeros(X.size + 1, dtype=torch.float32, device=device)
+  flat[1:] = helpers.to_dev(X, device).reshape(-1)
+  Xview = flat[1:].view(100, 64)
+  assert Xview.data_ptr() % 16 == 4 and Xview.is_contiguous()
+  out = ista_fista.run(Xview, helpers.to_dev(D, device), 0.02, 20,
+                       stepsize=eta, precision='f32')
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), 1e-5,
+                             'misaligned patches', max_flip_mag=2e-6)

@@ -267,14 +267,20 @@ static int fc_ista_fista_impl(const float* images, const float* dictionary,
               "VTC_F16X3, VTC_BF16X3 or VTC_F32");
     return VTC_ERR_UNSUPPORTED;
   }
-  // 8x8 patches against 64 / 128 atoms, exact f32: everything on the CU
-  if (precision == VTC_F32 && early_stopping_epsilon < 0.f &&
+  // (the register-resident kernels move patches and codes as float4)
+  const bool aligned16 =
+      ((reinterpret_cast<uintptr_t>(images) |
+        reinterpret_cast<uintptr_t>(dictionary) |
+        reinterpret_cast<uintptr_t>(codes) |
+        reinterpret_cast<uintptr_t>(initial_codes)) & 15) == 0;
+  // 8x8 patches against 64 / 128 / 192 atoms, exact f32: everything on the CU
+  if (precision == VTC_F32 && early_stopping_epsilon < 0.f && aligned16 &&
       num_iters <= fused_max_iters() && small_shape_supported(n, s))
     return run_small(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
                      variant, threshold, iters_run, st);
   // 12x12 patches against 288 / 576 atoms, exact f32: state on the CU
-  if (precision == VTC_F32 && early_stopping_epsilon < 0.f &&
+  if (precision == VTC_F32 && early_stopping_epsilon < 0.f && aligned16 &&
       num_iters <= fused_max_iters() && chip16_shape_supported(n, s))
     return run_chip16(images, dictionary, initial_codes, codes, b, n, s,
                       stepsize, stepsize_dev, sparsity_weight, num_iters,
