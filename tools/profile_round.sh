@@ -39,6 +39,9 @@ python3 tools/pmc_summary.py $out conv_ > $out/conv_pmc.txt; cat $out/conv_pmc.t
 VTC_CONV_STAMPS=1 timeout -k 10 100 python3 tools/run_configs.py conv 2>&1 | grep -A10 "do_synth=1" | tail -11 > $out/conv_stamps.txt; cat $out/conv_stamps.txt
 [ -x tools/micro/lds_unaligned ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/lds_unaligned.hip -o tools/micro/lds_unaligned 2>/dev/null
 timeout -k 10 60 tools/micro/lds_unaligned > $out/lds_unaligned.txt 2>&1; cat $out/lds_unaligned.txt
+echo "== fully-connected shapes outside the headline kernel, reproducibility soak"
+timeout -k 10 300 python3 tools/time_fc_shapes.py 2>&1 | grep -v amdgpu > $out/fc_other_shapes.txt; cat $out/fc_other_shapes.txt
+timeout -k 10 600 python3 tools/soak_reproducibility.py 150 2>&1 | grep -v amdgpu > $out/soak_reproducibility.txt; tail -2 $out/soak_reproducibility.txt
 echo "== example sizes"
 timeout -k 10 200 python3 tools/time_fc_example.py 2>&1 | grep -v amdgpu > $out/example_sizes.txt
 timeout -k 10 200 python3 tools/time_conv_example.py 2>&1 | grep -v amdgpu >> $out/example_sizes.txt; cat $out/example_sizes.txt
