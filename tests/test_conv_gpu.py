@@ -154,6 +154,8 @@ def _conv_case(seed, k, s, height, width, b=2, scale=0.5):
 
 @pytest.mark.parametrize('k,s,height,width', [(11, 32, 70, 93),
                                               (11, 128, 48, 60),
+                                              (11, 192, 37, 70),
+                                              (5, 96, 64, 33),
                                               (11, 9, 64, 64),
                                               (5, 40, 41, 130),
                                               (8, 64, 50, 77),
