@@ -1252,8 +1252,18 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
     int64_t items) {
   constexpr int NT = (K + 1) / 2;                  // accumulator tiles (2 dy each)
   constexpr int WROWS = kCxGradRows + 2 * NT;      // window rows incl. padding
-  __shared__ __attribute__((aligned(16))) uint16_t Rh[WROWS * kCxAnaPitch];
-  __shared__ __attribute__((aligned(16))) uint16_t Rl[WROWS * kCxAnaPitch];
+  // The window operand of a lane starts at pixel 16 ks + 8 half + dx: a
+  // 16-byte LDS read at 2-byte alignment, 52-64 LDS cycles per wave against 4
+  // aligned (tools/micro/lds_unaligned.hip) -- 12 such reads per 18 MFMAs made
+  // this kernel LDS-bound 4x over.  As in the fused iteration kernel the
+  // window is kept in 4 copies, copy c shifted by c pixels, and a lane reads
+  // two 8-byte aligned halves from copy dx & 3; the copy stride is padded to
+  // 16 or 48 (mod 64) dwords so that the copies sit on disjoint banks.
+  constexpr int PLANE = WROWS * kCxAnaPitch;       // elements
+  constexpr int kPadDw =
+      (PLANE % 64 == 16 || PLANE % 64 == 48) ? 0 : (16 - PLANE % 64 + 64) % 64;
+  constexpr int COPY = 2 * PLANE + 2 * kPadDw;     // hi plane, lo plane, pad
+  __shared__ __attribute__((aligned(16))) uint16_t Wc[4 * COPY + 8];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -1278,13 +1288,21 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
     __syncthreads();                               // window of the last item
     {
       const float* Rimg = R + img * g.H * (int64_t)g.W;
-      for (int e = tid; e < WROWS * kCxAnaPitch; e += 256) {
+      for (int e = tid; e < PLANE; e += 256) {
         const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
         const int y = u0 + ry, x = v0 + rx;
         const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
         const __bf16 h = (__bf16)v;
-        Rh[e] = cx_bits(h);
-        Rl[e] = cx_bits((__bf16)(v - (float)h));
+        const uint16_t hb = cx_bits(h);
+        const uint16_t lb = cx_bits((__bf16)(v - (float)h));
+        // pixel x of a row sits at position x - c of copy c; the first c
+        // pixels of a row land on the last positions of the row (or plane)
+        // before, which no read reaches (reads end at position 78 of 88)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          Wc[8 + c * COPY + e - c] = hb;
+          Wc[8 + c * COPY + PLANE + e - c] = lb;
+        }
       }
     }
     __syncthreads();
@@ -1316,14 +1334,17 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
         cx_split8(a, ah, al);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int off = (lu + 2 * nt + dyi) * kCxAnaPitch + 16 * ks +
-                          8 * half + dx;
-          const CxUnaligned16 h =
-              *reinterpret_cast<const CxUnaligned16*>(Rh + off);
-          const CxUnaligned16 l =
-              *reinterpret_cast<const CxUnaligned16*>(Rl + off);
-          const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, h);
-          const cx_bf16x8 bl = __builtin_bit_cast(cx_bf16x8, l);
+          const uint16_t* bp = Wc + 8 + (dx & 3) * COPY +
+                               (lu + 2 * nt + dyi) * kCxAnaPitch + 16 * ks +
+                               8 * half + (dx & ~3);
+          const uint2 h0 = *reinterpret_cast<const uint2*>(bp);
+          const uint2 h1 = *reinterpret_cast<const uint2*>(bp + 4);
+          const uint2 l0 = *reinterpret_cast<const uint2*>(bp + PLANE);
+          const uint2 l1 = *reinterpret_cast<const uint2*>(bp + PLANE + 4);
+          const cx_bf16x8 bh = __builtin_bit_cast(
+              cx_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          const cx_bf16x8 bl = __builtin_bit_cast(
+              cx_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt],
                                                             0, 0, 0);
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt],
