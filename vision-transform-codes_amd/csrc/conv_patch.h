@@ -26,7 +26,8 @@ static bool patch_geometry(const ConvGeo& g) {
   const int64_t cover = (int64_t)ceil_div(g.kh, g.sv) * ceil_div(g.kw, g.sh);
   const int64_t ctaps = (int64_t)g.c * g.kh * g.kw;
   return (g.sv > 1 || g.sh > 1) && cover <= 16 && ctaps <= 8192 &&
-         g.b <= 65535;
+         g.b <= 65535 &&
+         (int64_t)g.b * g.ch * g.cw < ((int64_t)1 << 31);  // 32-bit positions
 }
 
 static size_t patch_workspace_bytes(const ConvGeo& g) {
@@ -94,7 +95,11 @@ struct EpiPatchProx {
   double local;
   __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
                                              int) {
-    const int64_t img = col / map, pq = col - img * map;
+    // (positions fit 32 bits -- patch_geometry limits the route to small
+    // maps -- and a 64-bit division per output element cost more than the
+    // proximal step itself)
+    const unsigned img32 = (unsigned)col / (unsigned)map;
+    const int64_t img = img32, pq = col - img * map;
     const int64_t idx = (img * s + row) * map + pq;
     const float yv = Y[idx];
     const float c = shrink(sub_rn(yv, mul_rn(pp.eta, v)), pp.cutoff, pp.mode);
