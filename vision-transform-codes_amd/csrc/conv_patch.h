@@ -43,6 +43,22 @@ __global__ void conv_im2col_kernel(const float* __restrict__ R,
   const int64_t map = (int64_t)g.ch * g.cw;
   const int64_t total = g.b * map * ctaps;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (total < ((int64_t)1 << 31)) {
+    // 32-bit index arithmetic (five 64-bit divisions per element were a fifth
+    // of an iteration at the reference's example geometry)
+    const unsigned cw = (unsigned)g.cw, ch = (unsigned)g.ch;
+    const unsigned kw = (unsigned)g.kw, kh = (unsigned)g.kh;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+         i < (unsigned)total; i += (unsigned)stride) {
+      const unsigned pos = i / (unsigned)ctaps, t = i - pos * (unsigned)ctaps;
+      const unsigned dx = t % kw, dy = (t / kw) % kh, chan = t / (kw * kh);
+      const unsigned q = pos % cw, pc = pos / cw;
+      const unsigned p = pc % ch, img = pc / ch;
+      P[i] = R[(((int64_t)img * g.c + chan) * g.H + p * g.sv + dy) *
+                   (int64_t)g.W + q * g.sh + dx];
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += stride) {
     const int t = (int)(i % ctaps);
@@ -64,9 +80,21 @@ __global__ void conv_col2im_residual_kernel(const float* __restrict__ Q,
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += stride) {
-    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H);
-    const int chan = (int)((i / ((int64_t)g.W * g.H)) % g.c);
-    const int64_t img = i / ((int64_t)g.W * g.H * g.c);
+    int x, y, chan;
+    int64_t img;
+    if (total < ((int64_t)1 << 31)) {               // 32-bit index arithmetic
+      const unsigned i32 = (unsigned)i, W = (unsigned)g.W, H = (unsigned)g.H;
+      const unsigned row = i32 / W, plane = row / H;
+      x = (int)(i32 - row * W);
+      y = (int)(row - plane * H);
+      chan = (int)(plane % (unsigned)g.c);
+      img = plane / (unsigned)g.c;
+    } else {
+      x = (int)(i % g.W);
+      y = (int)((i / g.W) % g.H);
+      chan = (int)((i / ((int64_t)g.W * g.H)) % g.c);
+      img = i / ((int64_t)g.W * g.H * g.c);
+    }
     int p_lo = (y - g.kh + g.sv) / g.sv;          // ceil((y - kh + 1) / sv)
     if (y - g.kh + 1 <= 0) p_lo = 0;
     int p_hi = y / g.sv;
