@@ -1205,8 +1205,19 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
   const int64_t total = g.b * (int64_t)g.H * g.W;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % g.W), y = (int)((i / g.W) % g.H);
-    const int64_t img = i / ((int64_t)g.W * g.H);
+    int x, y;
+    int64_t img;
+    if (total < ((int64_t)1 << 31)) {               // 32-bit index arithmetic
+      const unsigned i32 = (unsigned)i, W = (unsigned)g.W;
+      const unsigned row = i32 / W, im = row / (unsigned)g.H;
+      x = (int)(i32 - row * W);
+      y = (int)(row - im * (unsigned)g.H);
+      img = im;
+    } else {
+      x = (int)(i % g.W);
+      y = (int)((i / g.W) % g.H);
+      img = i / ((int64_t)g.W * g.H);
+    }
     int tu_lo = (y - F::TH + F::ROWS) / F::ROWS;    // ceil((y - TH + 1) / ROWS)
     if (y - F::TH + 1 <= 0) tu_lo = 0;
     int tu_hi = y / F::ROWS;
