@@ -34,7 +34,8 @@
  *     one flag back per iteration exactly like the reference's
  *     `stop_early = (avg < eps)` does (ista_fista.py:143-144).
  *   - no allocation inside: scratch comes from the caller as `workspace`, sized
- *     by the matching *_workspace_bytes() query.
+ *     by the matching *_workspace_bytes() query.  The per-device constants of
+ *     the library (the 64 KiB FISTA momentum table) are placed by vtc_init().
  *   - return value: VTC_OK or a VTC_ERR_* code; vtc_last_error() gives text.
  *   - the gradient/apply split of the dictionary update is where a data-parallel
  *     caller places its all-reduce: gradient sums are un-normalised sums over
@@ -50,7 +51,7 @@
 extern "C" {
 #endif
 
-#define VTC_ABI_VERSION 3
+#define VTC_ABI_VERSION 4
 
 enum vtc_status {
   VTC_OK = 0,
@@ -84,6 +85,13 @@ enum vtc_precision {
 const char* vtc_version(void);
 const char* vtc_last_error(void);
 int vtc_abi_version(void);
+/* Places the library's per-device constants on the CURRENT HIP device: the
+ * FISTA momentum table beta_k = (t_k - 1) / t_{k+1} (ista_fista.py:123-127,
+ * float64 recurrence rounded to f32, 16384 entries: one hipMalloc and one
+ * blocking 64 KiB copy).  Thread-safe and idempotent; call it once per device
+ * before enqueueing work if the first inference call must not block.  An
+ * inference entry point that finds the device unprepared calls it itself. */
+int vtc_init(void);
 
 /* ---- Lipschitz step ---------------------------------------------------- */
 /* gram = A^T A (transpose_a = 1, A is (rows, cols), gram is (cols, cols)) or
@@ -94,14 +102,20 @@ int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
              float* gram, void* stream);
 /* Largest eigenvalue of a symmetric (n,n) matrix, n <= 1024, replacing the
  * `torch.symeig(...)[0][-1]` of ista_fista.py:73-74: single-workgroup Lanczos
- * with full re-orthogonalisation + Sturm counts.  out (device, 2 floats) =
- * [lambda_max, 1/lambda_max].  n <= 256 keeps the Krylov basis in LDS and
- * needs no workspace (NULL, 0); 256 < n <= 1024 keeps it in the workspace.
- * Larger n: VTC_ERR_UNSUPPORTED (the caller then uses a library eigen-solver). */
+ * + Sturm counts.  out (device, 3 floats) = [lambda_max, 1/lambda_max,
+ * converged].  A Ritz value approaches lambda_max from below, so the kernel
+ * checks itself: the top Ritz value of all steps against that of the steps up
+ * to 8 earlier, going on (n <= 256: up to min(2n, 256) steps) while they differ
+ * by more than 1e-7 relative; converged = 1.0 when they agree or the Krylov
+ * space is exhausted, 0.0 when the step limit ended the iteration -- the
+ * reference's symeig is exact (ista_fista.py:72-80), a caller should treat 0
+ * like its failure.  n <= 256 needs no workspace (NULL, 0); 256 < n <= 1024
+ * keeps the Krylov basis in the workspace.  Larger n: VTC_ERR_UNSUPPORTED (the
+ * caller then uses a library eigen-solver). */
 size_t vtc_lambda_max_workspace_bytes(int64_t n);
 int vtc_lambda_max(const float* symmetric, int64_t n, float* out,
                    void* workspace, size_t workspace_bytes, void* stream);
-/* Same; the kernel also stores the two floats through host_mirror (may be
+/* Same; the kernel also stores the three floats through host_mirror (may be
  * NULL), a device-visible HOST pointer (pinned memory): a caller that keeps
  * eta on the device can still notice a failed eigen-solve -- the reference's
  * symeig raises there, ista_fista.py:75-79 -- without a copy or a wait. */

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_loads_and_reports_version():
   import vtc_hip
   lib = vtc_hip.load_library()
-  assert lib.vtc_abi_version() == vtc_hip.ABI_VERSION == 3
+  assert lib.vtc_abi_version() == vtc_hip.ABI_VERSION == 4
   assert b'gfx950' in lib.vtc_version()
 
 

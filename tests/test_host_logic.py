@@ -218,3 +218,113 @@ def test_data_parallel_update_matches_single_process(tmp_path):
   sc_oracle.fc_steepest_descent(X, full, C, stepsize=0.1)
   assert helpers.rel_err(r0['dict'].numpy(), full.numpy()) < 1e-6
   assert helpers.rel_err(r0['energy'].numpy(), (C * C).sum(0).numpy()) < 1e-6
+
+
+def _rp_worker(rank, world, port, out_dir):
+  """dict_element_rp_schedule under data parallelism: every rank makes its OWN
+  random choice (different generators), rank 0's wins everywhere; then one
+  update step through the persistent flat buffer (energy + gradient slices,
+  summed in place by ONE collective without packing)."""
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..',
+                                  'vision-transform-codes_amd'))
+  from vtc_hip import parallel
+  torch.set_num_threads(2)
+  parallel.enable()
+  np.random.seed(100 + rank)                 # the ranks' generators differ
+  torch.manual_seed(200 + rank)
+  D = torch.from_numpy(helpers.unit_rows(8, 12, 16))
+  groups = [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]]
+  hessian = torch.arange(12, dtype=torch.float32)
+  results = {}
+  for action in ('reset', 'prune'):
+    mine = D.clone()
+    my_groups = [list(g) for g in groups]
+    affected = np.random.choice(np.arange(12), 3, replace=False)
+    new = mine
+    if rank == 0:                            # what rank 0's filter returns
+      if action == 'reset':
+        mine[torch.as_tensor(affected)] = torch.randn(3, 16)
+      else:
+        keep = torch.ones(12, dtype=torch.bool)
+        keep[torch.as_tensor(affected)] = False
+        new = mine[keep]
+        dropped = set(int(a) for a in affected)
+        for g in range(len(my_groups)):
+          my_groups[g] = [a for a in my_groups[g] if a not in dropped]
+    else:
+      affected = []                          # a non-zero rank decides nothing
+    new, affected, _ = parallel.broadcast_reset_or_prune(new, affected,
+                                                         my_groups)
+    if action == 'reset':
+      assert new is mine                     # in place: callers hold aliases
+    keep = torch.ones(12, dtype=torch.bool)
+    if action == 'prune':
+      keep[torch.as_tensor(np.asarray(affected, dtype=np.int64))] = False
+    results[action] = {'dict': new.clone(), 'affected': [int(a) for a in affected],
+                       'groups': my_groups, 'hessian': hessian[keep].clone()}
+  # one update step through the flat buffer
+  before_c, before_p = parallel.collectives_issued, parallel.packed_copies
+  for step in range(2):                      # the second step re-uses the buffer
+    energy = parallel.take((12,), 'cpu')
+    energy.copy_(torch.full((12,), float(rank + 1)))
+    ran = []
+    parallel.defer(energy, lambda: ran.append(energy.clone()))
+    grad = parallel.take((12, 16), 'cpu')
+    grad.copy_(torch.full((12, 16), 10.0 * (rank + 1)))
+    parallel.all_reduce_sum_(grad)
+    assert torch.equal(ran[0], torch.full((12,), 3.0))
+    assert torch.equal(grad, torch.full((12, 16), 30.0))
+  assert parallel.collectives_issued - before_c == 2
+  # the first step may pack (the buffer is created by its first take; both
+  # slices come from the same buffer here), the second must not
+  assert parallel.packed_copies - before_p == 0
+  # a plugin that dies between defer() and its reduce leaves nothing behind
+  parallel.defer(parallel.take((12,), 'cpu'), lambda: None)
+  parallel.drop_deferred()
+  parallel.flush_deferred()
+  assert parallel.collectives_issued - before_c == 2
+  torch.save(results, os.path.join(out_dir, 'rp_rank%d.pt' % rank))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_reset_and_prune_are_rank0s_decision_everywhere(tmp_path):
+  world = 2
+  mp.spawn(_rp_worker, args=(world, _free_port(), str(tmp_path)),
+           nprocs=world, join=True)
+  r0 = torch.load(tmp_path / 'rp_rank0.pt', weights_only=True)
+  r1 = torch.load(tmp_path / 'rp_rank1.pt', weights_only=True)
+  for action in ('reset', 'prune'):
+    assert torch.equal(r0[action]['dict'], r1[action]['dict'])
+    assert r0[action]['affected'] == r1[action]['affected']
+    assert r0[action]['groups'] == r1[action]['groups']
+    assert r0[action]['hessian'].shape == r1[action]['hessian'].shape
+  assert r0['prune']['dict'].shape[0] == 9 == r0['prune']['hessian'].shape[0]
+  assert sum(len(g) for g in r0['prune']['groups']) == 9
+
+
+def test_checkpoint_loader_reads_arrays_only(tmp_path):
+  """load_newest_dictionary_checkpoint: newest iteration by number, stray
+  suffixes ignored, and a pickle that names anything but a numpy array is
+  refused instead of executed."""
+  import pickle
+  from training import sparse_coding as trainer
+  arr = np.arange(12, dtype=np.float32).reshape(3, 4)
+  for it in (5, 40):
+    with open(tmp_path / ('checkpoint_dictionary_iter_%d' % it), 'wb') as f:
+      pickle.dump(arr + it, f)
+  (tmp_path / 'checkpoint_dictionary_iter_90.bak').write_bytes(b'junk')
+  got = trainer.load_newest_dictionary_checkpoint(tmp_path)
+  assert np.array_equal(got, arr + 40)
+
+  class Evil(object):
+    def __reduce__(self):
+      return (os.system, ('true',))
+  with open(tmp_path / 'checkpoint_dictionary_iter_99', 'wb') as f:
+    pickle.dump(Evil(), f)
+  with pytest.raises(pickle.UnpicklingError):
+    trainer.load_newest_dictionary_checkpoint(tmp_path)

@@ -19,6 +19,6 @@ for s, n in ((256, 256), (1024, 256), (128, 121)):
   o = out.cpu().numpy()
   names = ['A matvec', 'B update', 'bounds', 'solve']
   print('n=%d s=%d lambda %.6f (eigvalsh %.6f) total %.0f cycles' % (
-      n, s, o[0], float(torch.linalg.eigvalsh(G.double())[-1]), o[2:6].sum()))
+      n, s, o[0], float(torch.linalg.eigvalsh(G.double())[-1]), o[3:7].sum()))
   for k, name in enumerate(names):
-    print('   %-10s %9.0f cycles' % (name, o[2 + k]))
+    print('   %-10s %9.0f cycles' % (name, o[3 + k]))

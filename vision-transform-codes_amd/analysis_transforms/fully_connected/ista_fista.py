@@ -60,6 +60,7 @@ def run(images, dictionary, sparsity_weight, num_iters, variant='fista',
   b, n = images.shape
   s = dictionary.shape[0]
   assert dictionary.shape[1] == n
+  vtc_hip.prepare_device(images.device)
   if initial_codes is not None:
     initial_codes = vtc_hip.require_device_tensor(
         initial_codes, 'initial_codes').contiguous()

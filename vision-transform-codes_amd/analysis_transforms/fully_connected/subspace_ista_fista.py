@@ -39,6 +39,7 @@ def run(images, dictionary, group_assignments, sparsity_weight,
   dictionary = vtc_hip.require_device_tensor(
       dictionary, 'dictionary').contiguous()
   b, n = images.shape
+  vtc_hip.prepare_device(images.device)
   s = dictionary.shape[0]
   device = images.device
   stream = vtc_hip.current_stream(device)

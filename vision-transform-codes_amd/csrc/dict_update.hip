@@ -92,15 +92,11 @@ static int gradient_slices(int64_t b, int64_t n, int64_t s) {
 }
 
 // ------------------------------------------------------------------ apply
-// One wave per atom (dictionary row).
-__global__ __launch_bounds__(256) void fc_apply_kernel(
+__device__ __forceinline__ void fc_apply_row(
     float* __restrict__ D, const float* __restrict__ G,
     const float* __restrict__ hess, const float* __restrict__ P,
     float alignment_penalty, float batch_f, float stepsize, float lowest,
-    int normalize, int64_t s, int64_t n) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= s) return;
+    int normalize, int64_t row, int64_t n, int lane) {
   float* d = D + row * n;
   const float* g = G + row * n;
   const float* p = P ? P + row * n : nullptr;
@@ -120,6 +116,24 @@ __global__ __launch_bounds__(256) void fc_apply_kernel(
   for (int64_t j = lane; j < n; j += 64) d[j] = d[j] / norm;
 }
 
+// One wave per atom (dictionary row); a block owns `rows_per_block`
+// consecutive rows.  The update is in place, and two blocks on different XCDs
+// must not read-modify-write parts of one 128-byte line (the L2s are not
+// coherent within a launch): the host picks rows_per_block so that a block's
+// footprint is a whole number of lines (4 rows for 16x16 patches, 32 for an
+// odd pixel count).
+__global__ __launch_bounds__(256) void fc_apply_kernel(
+    float* __restrict__ D, const float* __restrict__ G,
+    const float* __restrict__ hess, const float* __restrict__ P,
+    float alignment_penalty, float batch_f, float stepsize, float lowest,
+    int normalize, int64_t s, int64_t n, int rows_per_block) {
+  const int lane = threadIdx.x & 63;
+  const int64_t first = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t last = first + rows_per_block < s ? first + rows_per_block : s;
+  for (int64_t row = first + (threadIdx.x >> 6); row < last; row += 4)
+    fc_apply_row(D, G, hess, P, alignment_penalty, batch_f, stepsize, lowest,
+                 normalize, row, n, lane);
+}
 // ------------------------------------------------- alignment penalty (a7)
 // One block per group.  Rows of the group are copied to LDS, the m x m table
 // of cosines is formed, then every thread owns columns of the gradient rows.
@@ -428,11 +442,16 @@ extern "C" int vtc_fc_dict_apply(float* dictionary, const float* grad_sum,
   VTC_REQUIRE(dictionary && grad_sum, "vtc_fc_dict_apply: null pointer");
   VTC_REQUIRE(s > 0 && n > 0 && global_batch > 0,
               "vtc_fc_dict_apply: bad sizes");
-  hipLaunchKernelGGL(fc_apply_kernel, dim3((unsigned)ceil_div(s, 4)),
+  // rows per block: a multiple of 4 whose bytes are a multiple of 128 (see the
+  // kernel); a dictionary that does not start on a line goes to one block
+  int64_t rows = 32;
+  while (rows > 4 && ((rows / 2) * n * 4) % 128 == 0) rows /= 2;
+  if (reinterpret_cast<uintptr_t>(dictionary) % 128 != 0) rows = s;
+  hipLaunchKernelGGL(fc_apply_kernel, dim3((unsigned)ceil_div(s, rows)),
                      dim3(256), 0, as_stream(stream), dictionary, grad_sum,
                      hessian_diagonal, penalty_grad, alignment_penalty,
                      (float)global_batch, stepsize, lowest_code_val, normalize,
-                     s, n);
+                     s, n, (int)rows);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }

@@ -51,6 +51,7 @@
 #include "fused_common.h"
 
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 namespace vtc {
@@ -519,11 +520,9 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
                    : (k == 2) ? cold4.z : cold4.w;
     const float c = sub_rn(Y[p][e], mul_rn(eta, Gp[e]));
     const float cn = shrink_fast<MODE>(c, cutoff_l);
-    // ISTA runs with beta = 0: y = c + 0 * (c - c_old) = c exactly for finite
-    // codes.  (A code that has already overflowed to inf gives NaN one
-    // iteration before the reference's `y = codes` would -- ista_fista.py:133
-    // -- whose next residual inf * D - X is NaN as well.)
-    Y[p][e] = add_rn(cn, mul_rn(beta, sub_rn(cn, co)));
+    // ISTA: y = codes (ista_fista.py:133), not codes + 0 * (codes - old):
+    // a code that has overflowed to inf stays inf as it does there
+    Y[p][e] = fista ? add_rn(cn, mul_rn(beta, sub_rn(cn, co))) : cn;
     cn4[k] = cn;
     if (k == 3) {
       if (p < CREG) {
@@ -647,6 +646,15 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
 }
 
 }  // namespace vtc
+
+// Experiment kept out of the library (profiles/r03_fused_onepacking.txt): a
+// variant that keeps part of each phase's dictionary tile in LDS and reads it
+// back transposed instead of streaming packT.  Build with
+// -DVTC_EXPERIMENT_ONE_PACKING, run with VTC_FUSED_1P=2|3.
+#ifdef VTC_EXPERIMENT_ONE_PACKING
+#include "../../tools/micro/fc_fused1p.h"
+#endif
+
 namespace vtc {
 
 // -------------------------------------------------------------------- host
@@ -720,9 +728,87 @@ static int launch_stamped(FusedParams P, hipStream_t st) {
   return VTC_OK;
 }
 
+#ifdef VTC_EXPERIMENT_ONE_PACKING
+// One-packing variant (fc_fused1p.h), three-product modes.
+template <int NPH, int MODE, bool F16, int NT>
+static int launch_fused1p(const FusedParams& P, hipStream_t st) {
+  using L = Fused1pLds<NT>;
+  auto kernel = fused1p_kernel<NPH, MODE, F16, NT>;
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+  }
+  const unsigned grid = (unsigned)ceil_div(P.b, kFP);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+template <int NPH, bool F16, int NT>
+static int launch_stamped1p(FusedParams P, hipStream_t st) {
+  using L = Fused1pLds<NT>;
+  auto kernel = fused1p_kernel<NPH, VTC_SOFT, F16, NT, true>;
+  unsigned long long* dev = nullptr;
+  VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
+  VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
+  VTC_HIP_CHECK(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+  P.stamps = dev;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(256),
+                     L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  unsigned long long host[8];
+  VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost,
+                               st));
+  VTC_HIP_CHECK(hipStreamSynchronize(st));
+  VTC_HIP_CHECK(hipFree(dev));
+  const char* names[5] = {"step1", "epilogue", "barrier1", "step3",
+                          "barrier2+x"};
+  double total = 0;
+  for (int k = 0; k < 5; ++k) total += (double)host[k];
+  const double per = (double)host[7] * P.num_iters * NPH;
+  for (int k = 0; k < 5; ++k)
+    fprintf(stderr, "[vtc stamps 1p] %-10s %5.1f%%  %8.0f cycles/phase/wave\n",
+            names[k], 100.0 * host[k] / total, host[k] / per);
+  return VTC_OK;
+}
+
+template <int NPH, bool F16>
+static int dispatch_mode1p(const FusedParams& P, int threshold, int nt,
+                           hipStream_t st) {
+  static const bool stamps = getenv("VTC_FUSED_STAMPS") != nullptr;
+  if (stamps && threshold == VTC_SOFT && NPH == 8)
+    return nt == 2 ? launch_stamped1p<NPH, F16, 2>(P, st)
+                   : launch_stamped1p<NPH, F16, 3>(P, st);
+#define VTC1_CASE(M)                                              \
+  case M:                                                         \
+    return nt == 2 ? launch_fused1p<NPH, M, F16, 2>(P, st)        \
+                   : launch_fused1p<NPH, M, F16, 3>(P, st);
+  switch (threshold) {
+    VTC1_CASE(VTC_SOFT)
+    VTC1_CASE(VTC_SOFT_NONNEG)
+    VTC1_CASE(VTC_HARD)
+    default:
+      return nt == 2 ? launch_fused1p<NPH, VTC_HARD_NONNEG, F16, 2>(P, st)
+                     : launch_fused1p<NPH, VTC_HARD_NONNEG, F16, 3>(P, st);
+  }
+#undef VTC1_CASE
+}
+
+#endif
+
 template <int NPH, int NP, bool F16>
 static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
   static const bool stamps = getenv("VTC_FUSED_STAMPS") != nullptr;
+#ifdef VTC_EXPERIMENT_ONE_PACKING
+  static const int one_packing =
+      getenv("VTC_FUSED_1P") ? atoi(getenv("VTC_FUSED_1P")) : 0;
+  if (NP == 2 && one_packing >= 2)
+    return dispatch_mode1p<NPH, F16>(P, threshold, one_packing, st);
+#endif
   if (stamps && threshold == VTC_SOFT && NPH == 8 && NP == 2)
     return launch_stamped<NPH, NP, F16>(P, st);
   switch (threshold) {
@@ -748,13 +834,16 @@ static int dispatch_phases(const FusedParams& P, int threshold,
 
 // The FISTA momentum table beta_k = (t_k - 1) / t_{k+1} (ista_fista.py:123-127,
 // float64 recurrence rounded to f32) does not depend on the call: one copy per
-// device, filled from the host table on the first call there (a blocking
-// 64 KiB copy, once); afterwards a call only enqueues.
+// device, placed by vtc_init() -- or by the first inference call on a device
+// nobody prepared (one hipMalloc and a blocking 64 KiB copy, under a lock);
+// afterwards a call only enqueues.
 constexpr int kBetaTable = 16384;
 const float* fista_beta_table_on_this_device() {
   static float* tables[64] = {nullptr};
+  static std::mutex guard;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
+  std::lock_guard<std::mutex> lock(guard);
   if (tables[dev]) return tables[dev];
   std::vector<float> host;
   fista_betas(kBetaTable, &host);
@@ -848,3 +937,11 @@ int run_fused(const float* images, const float* dictionary,
 }
 
 }  // namespace vtc
+
+extern "C" int vtc_init(void) {
+  if (!vtc::fista_beta_table_on_this_device()) {
+    vtc::set_error("vtc_init: could not place the momentum table on the device");
+    return VTC_ERR_HIP;
+  }
+  return VTC_OK;
+}

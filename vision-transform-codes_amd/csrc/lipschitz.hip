@@ -144,6 +144,29 @@ __device__ double tridiagonal_lambda_max_block(const double* alpha,
   return 0.5 * (lo + hi);
 }
 
+// True when every eigenvalue of the leading m x m block of the tridiagonal
+// matrix lies below x (Sturm count == m), by the division-free polynomial
+// recurrence above; every thread evaluates the same point.  Used once per
+// solve for the convergence test, so it is a plain loop.
+__device__ bool tridiagonal_all_below(const double* alpha, const double* beta2,
+                                      int m, double x) {
+  double p_prev = 0.0, p = 1.0;
+  int below = 0;
+  for (int i = 0; i < m; ++i) {
+    const double b2 = i > 0 ? beta2[i - 1] : 0.0;
+    const double pn = fma(alpha[i] - x, p, -b2 * p_prev);
+    below += ((__double2hiint(pn) ^ __double2hiint(p)) >> 31) & 1;
+    p_prev = p;
+    p = pn;
+    if ((i & 7) == 7) {
+      const int e = ilogb(p);
+      p = ldexp(p, -e);
+      p_prev = ldexp(p_prev, -e);
+    }
+  }
+  return below == m;
+}
+
 // Wave-wide sums on the DPP network (row shifts, then the two row broadcasts):
 // a handful of VALU instructions, where __shfl_xor goes through ds_bpermute at
 // an LDS round trip per stage -- this kernel is one workgroup running a chain
@@ -197,17 +220,20 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // per step against 2600 here).  min(96, 2n) steps; measured against LAPACK on
 // dictionary Grams of every shape in tests/test_lipschitz_gpu.py: <= 4e-7.
 constexpr int kLzThreads = 512;
+constexpr int kLzMaxSteps = 256;   // upper end of the step count (arrays)
+constexpr int kLzExtend = 16;      // steps added when the test below fails
+constexpr int kLzLookBack = 8;
 
 template <bool STAMP>
 __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
-    const float* __restrict__ G, int n, int k, float* __restrict__ out,
-    float* __restrict__ mirror) {
+    const float* __restrict__ G, int n, int k, int k_cap,
+    float* __restrict__ out, float* __restrict__ mirror) {
   __shared__ __attribute__((aligned(16))) float vcur[256];  // b_{j-1} v_j
   __shared__ __attribute__((aligned(16))) float partial[4][256];
   __shared__ double red_a[8], red_b[4];
-  __shared__ double alpha[kLanczosMaxK + 8];
-  __shared__ double beta[kLanczosMaxK + 8];
-  __shared__ double beta2[kLanczosMaxK + 8];
+  __shared__ double alpha[kLzMaxSteps + 8];
+  __shared__ double beta[kLzMaxSteps + 8];
+  __shared__ double beta2[kLzMaxSteps + 8];
   __shared__ int scratch[4];
   unsigned long long st_t0 = 0, st_acc[4] = {0, 0, 0, 0};
 #define LZ_STAMP(slot)                                                   \
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   }
   // padding rows of the tridiagonal matrix (see the solver): every row is a
   // padding row until the recurrence overwrites it
-  for (int i = tid; i < kLanczosMaxK + 8; i += kLzThreads) {
+  for (int i = tid; i < kLzMaxSteps + 8; i += kLzThreads) {
     alpha[i] = 1e30;
     beta2[i] = 0.0;
   }
@@ -268,7 +294,17 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   if (STAMP)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
 
-  for (int j = 0; j < k; ++j) {
+  // A Ritz value approaches lambda_max from below, so a fixed step count
+  // could hand back eta > 1 / L without a sign of it.  After the first
+  // `k` steps -- and after every kLzExtend more -- the top Ritz value of all
+  // steps is compared with that of the steps up to kLzLookBack earlier; the
+  // recurrence goes on (to at most k_cap steps) while they differ by more
+  // than 1e-7 relative, and the verdict is written next to the eigenvalue.
+  int target = k, j = 0;
+  bool exhausted = false, converged = false;
+  double lambda = 0.0;
+  for (;;) {
+  for (; j < target; ++j) {
     const float inv_b = (float)rb;
     const float vt = vcur[t] * inv_b;        // component t of v_j
     // ---- [A] w = G v_j: this thread's 64 rows of its two columns, and this
@@ -322,7 +358,10 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
     // NaN: what is left of w is rounding noise -- normalising it would feed
     // amplified garbage into the recurrence.  The tridiagonal matrix so far
     // already holds the spectrum of the reachable space.
-    if (!(b > 1e-5 * tscale)) break;
+    if (!(b > 1e-5 * tscale)) {
+      exhausted = true;
+      break;
+    }
     beta_prev = b;
   }
   __syncthreads();
@@ -335,21 +374,37 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   }
   LZ_STAMP(2)
   // 257^4 = 4.4e9 sections of a bracket a few lambda wide: below f32 resolution
+  const double coupling = beta2[steps - 1];
+  __syncthreads();
   if (tid == 0) beta2[steps - 1] = 0.0;   // no coupling into the padding rows
   __syncthreads();
-  const double lambda =
-      tridiagonal_lambda_max_block(alpha, beta2, steps, lo, hi, 4, scratch);
+  lambda = tridiagonal_lambda_max_block(alpha, beta2, steps, lo, hi, 4, scratch);
+  // converged: the Krylov space is exhausted (the tridiagonal matrix holds the
+  // whole reachable spectrum), or the steps up to kLzLookBack ago already had
+  // a Ritz value within 1e-7 of this one
+  converged = exhausted || steps <= kLzLookBack ||
+              !tridiagonal_all_below(alpha, beta2, steps - kLzLookBack,
+                                     lambda - 1e-7 * fabs(lambda));
+  if (converged || !(lambda == lambda) || steps >= k_cap) break;
+  __syncthreads();
+  if (tid == 0) beta2[steps - 1] = coupling;
+  target = steps + kLzExtend < k_cap ? steps + kLzExtend : k_cap;
+  __syncthreads();
+  }
   const float lf = (float)lambda;
   LZ_STAMP(3)
   if (tid == 0) {
+    const float flag = converged ? 1.f : 0.f;
     out[0] = lf;
     out[1] = 1.f / lf;  // the reference's `1. / lipschitz_constant` in f32
+    out[2] = flag;
     if (mirror) {       // host-visible copy for the caller's error channel
       mirror[0] = lf;
       mirror[1] = 1.f / lf;
+      mirror[2] = flag;
     }
     if (STAMP)
-      for (int q = 0; q < 4; ++q) out[2 + q] = (float)st_acc[q];
+      for (int q = 0; q < 4; ++q) out[3 + q] = (float)st_acc[q];
   }
 #undef LZ_STAMP
 }
@@ -380,7 +435,7 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
   __shared__ double alpha[kLanczosMaxK];
   __shared__ double beta[kLanczosMaxK];
   __shared__ int steps_done;
-  __shared__ int stop_flag;
+  __shared__ int stop_flag, loose_flag;
   __shared__ double last_ritz;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -399,6 +454,7 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
   if (t == 0) {
     steps_done = k;
     stop_flag = 0;
+    loose_flag = 0;
     last_ritz = -1.0;
   }
   double tscale = 0.0;
@@ -461,6 +517,8 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
         if (t == 0) {
           stop_flag = (last_ritz > 0.0 &&
                        fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
+          loose_flag = (last_ritz > 0.0 &&
+                        fabs(ritz - last_ritz) <= 1e-7 * fabs(ritz)) ? 1 : 0;
           last_ritz = ritz;
         }
       }
@@ -479,11 +537,18 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
     const double lambda = tridiagonal_lambda_max(alpha, beta, steps_done);
     const float lf = (float)lambda;
     if (t == 0) {
+      // converged: stopped by the test above, Krylov space exhausted (the
+      // last coupling vanished), or the latest of the 8-step comparisons
+      // within 1e-7
+      const bool ok = stop_flag || steps_done < k || loose_flag;
+      const float flag = ok ? 1.f : 0.f;
       out[0] = lf;
       out[1] = 1.f / lf;
+      out[2] = flag;
       if (mirror) {
         mirror[0] = lf;
         mirror[1] = 1.f / lf;
+        mirror[2] = flag;
       }
     }
   }
@@ -498,7 +563,7 @@ extern "C" size_t vtc_lambda_max_workspace_bytes(int64_t n) {
   return align_up((size_t)kLanczosMaxK * n * sizeof(float), 256);
 }
 
-// out: 2 floats on the device: [lambda_max, 1/lambda_max]
+// out: 3 floats on the device: [lambda_max, 1/lambda_max, converged (1 / 0)]
 static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
                            float* mirror, void* workspace,
                            size_t workspace_bytes, void* stream) {
@@ -521,23 +586,33 @@ static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
     VTC_LAUNCH_CHECK();
     return VTC_OK;
   }
-  // diagnostic: VTC_LANCZOS_STAMPS=1 and an `out` of 6 floats -> cycles per
-  // phase in out[2..5] (A mat-vec, B update, bounds, tridiagonal solve)
+  // diagnostic: VTC_LANCZOS_STAMPS=1 and an `out` of 7 floats -> cycles per
+  // phase in out[3..6] (A mat-vec, B update, bounds, tridiagonal solve)
   static const bool stamps = getenv("VTC_LANCZOS_STAMPS") != nullptr;
   // 96 steps: on every spectrum tried (dictionary Grams of all shapes in the
   // tests, clustered tops) the top Ritz value is within 2e-7 of LAPACK's
   // eigenvalue from step ~80 on; beyond convergence more steps only add
   // rounding noise from the copies of converged Ritz values
+  // (the kernel checks that itself and goes on, kLzExtend steps at a time up
+  // to k_cap = min(2n, kLzMaxSteps), while the value still moves)
   constexpr int kSteps = 96;
-  const int k_small = (int)(2 * n < kSteps ? 2 * n : kSteps);
+  int k_small = (int)(2 * n < kSteps ? 2 * n : kSteps);
+  int k_cap = (int)(2 * n < kLzMaxSteps ? 2 * n : kLzMaxSteps);
+  // test hook: VTC_LANCZOS_MAX_STEPS caps both (an unconverged solve on demand)
+  static const int forced_cap = getenv("VTC_LANCZOS_MAX_STEPS")
+                                    ? atoi(getenv("VTC_LANCZOS_MAX_STEPS")) : 0;
+  if (forced_cap > 0) {
+    k_cap = forced_cap < k_cap ? forced_cap : k_cap;
+    k_small = k_small < k_cap ? k_small : k_cap;
+  }
   if (stamps)
     hipLaunchKernelGGL(lanczos_lambda_max_kernel<true>, dim3(1),
                        dim3(kLzThreads), 0, as_stream(stream), symmetric,
-                       (int)n, k_small, out, mirror);
+                       (int)n, k_small, k_cap, out, mirror);
   else
     hipLaunchKernelGGL(lanczos_lambda_max_kernel<false>, dim3(1),
                        dim3(kLzThreads), 0, as_stream(stream), symmetric,
-                       (int)n, k_small, out, mirror);
+                       (int)n, k_small, k_cap, out, mirror);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }

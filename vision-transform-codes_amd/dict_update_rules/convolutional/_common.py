@@ -34,7 +34,7 @@ def descend(images_padded, dictionary, codes, kernel_stride, padding_dims,
   kernel_elems = geom.c * geom.kh * geom.kw
   ws = vtc_hip.workspace(
       lib.vtc_conv_dict_gradient_workspace_bytes(ctypes.byref(geom)), device)
-  grad_sum = torch.empty_like(dictionary)
+  grad_sum = parallel.take(tuple(dictionary.shape), device)
   scratch = torch.empty_like(dictionary)
   total_batch = parallel.global_batch(geom.b, device)
   # precision policy of the process (vtc_hip.set_default_precision): 'auto'

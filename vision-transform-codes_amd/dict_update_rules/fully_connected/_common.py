@@ -31,7 +31,7 @@ def descend(images, dictionary, codes, stepsize, num_iters,
   stream = vtc_hip.current_stream(device)
   ws = vtc_hip.workspace(lib.vtc_fc_dict_gradient_workspace_bytes(b, n, s),
                          device)
-  grad_sum = torch.empty((s, n), dtype=torch.float32, device=device)
+  grad_sum = parallel.take((s, n), device)
   total_batch = parallel.global_batch(b, device)
   for _ in range(num_iters):
     vtc_hip.check(lib.vtc_fc_dict_gradient(

@@ -170,7 +170,7 @@ class TrainingStep(object):
     device = codes.device
     ws = vtc_hip.workspace(
         lib.vtc_code_energy_workspace_bytes(b, s, positions), device)
-    energy = torch.empty(s, dtype=torch.float32, device=device)
+    energy = parallel.take((s,), device)
     stream = vtc_hip.current_stream(device)
     vtc_hip.check(lib.vtc_code_energy(
         vtc_hip.ptr(codes), b, s, positions, vtc_hip.ptr(energy),
@@ -206,8 +206,15 @@ class TrainingStep(object):
                          'subspace_sc_cheap_quadratic_descent'):
       kwargs.update({'group_assignments': self.groups,
                      'alignment_penalty': self.alignment_penalty})
-    self.dict_update.run(**kwargs)
-    parallel.flush_deferred()
+    try:
+      self.dict_update.run(**kwargs)
+      parallel.flush_deferred()
+    except BaseException:
+      # a plugin that failed before its all-reduce must not leave the code
+      # energy queued on this rank only (the next collective would then carry
+      # a different element count than on the other ranks)
+      parallel.drop_deferred()
+      raise
 
   def __call__(self, batch_images):
     codes = self.infer_codes(batch_images)
@@ -335,10 +342,27 @@ def load_newest_dictionary_checkpoint(checkpoint_dir):
   checkpoint_dictionary_iter_<i>, a pickled numpy array each)."""
   prefix = 'checkpoint_dictionary_iter_'
   iters = [int(p.name[len(prefix):]) for p in checkpoint_dir.iterdir()
-           if p.is_file() and p.name.startswith(prefix)]
+           if p.is_file() and p.name.startswith(prefix) and
+           p.name[len(prefix):].isdigit()]
   print('checkpoint idx: ', max(iters))
   with open(checkpoint_dir / (prefix + str(max(iters))), 'rb') as f:
-    return pickle.load(f)
+    return _ArrayUnpickler(f).load()
+
+
+class _ArrayUnpickler(pickle.Unpickler):
+  """Reads a pickled numpy array and nothing else: a checkpoint directory may
+  come from anywhere, and a plain pickle.load would run whatever callable the
+  file names."""
+  _ALLOWED = {('numpy.core.multiarray', '_reconstruct'),
+              ('numpy._core.multiarray', '_reconstruct'),
+              ('numpy', 'ndarray'), ('numpy', 'dtype')}
+
+  def find_class(self, module, name):
+    if (module, name) not in self._ALLOWED:
+      raise pickle.UnpicklingError(
+          'checkpoint refers to %s.%s: only plain numpy arrays are read' % (
+              module, name))
+    return super().find_class(module, name)
 
 
 def train_dictionary(training_image_dataset, validation_image_dataset,
@@ -409,9 +433,18 @@ def train_dictionary(training_image_dataset, validation_image_dataset,
         v_codes = torch.cat([
             step.infer_codes(v.to(init_dictionary.device))
             for v in validation_image_dataset])
-        step.replace_dictionary(*reset_or_prune_dict_elements(
-            step.dictionary, v_codes, entry['filter_type'], f_params,
-            entry['action']), action=entry['action'])
+        # data parallel: the selection and the replacement atoms come from
+        # each process's own numpy / torch CPU generators, so rank 0 decides
+        # and every rank adopts its dictionary (and its pruned group lists)
+        new_dictionary, affected = step.dictionary, []
+        if parallel.rank() == 0:
+          new_dictionary, affected = reset_or_prune_dict_elements(
+              step.dictionary, v_codes, entry['filter_type'], f_params,
+              entry['action'])
+        new_dictionary, affected, _ = parallel.broadcast_reset_or_prune(
+            new_dictionary, affected, step.groups)
+        step.replace_dictionary(new_dictionary, affected,
+                                action=entry['action'])
         init_dictionary = step.dictionary
         previous_dictionary = step.previous_dictionary
       if (ckpt_schedule is not None and total_iter_idx in ckpt_schedule and
@@ -570,6 +603,10 @@ def reset_or_prune_dict_elements(dictionary, codes, filter_type,
           if action == 'reset':
             _write_rows(dictionary, members[local], _noise_rows(
                 len(local), width, average_norm(gram, members), device))
+            # the reference takes each group's similarities and norms from the
+            # dictionary as it stands (:632-655): with overlapping groups a
+            # later group sees the rows just replaced
+            gram = _row_gram(dictionary)
           flagged.append(members[local])
       modify_these = np.array(flagged).flatten()
       if action == 'prune' and len(modify_these) > 0:

@@ -24,7 +24,7 @@ ISTA, FISTA = 0, 1
 SOFT, SOFT_NONNEG, HARD, HARD_NONNEG = range(4)
 F32, BF16X3, BF16, F16X3 = range(4)
 PRECISIONS = {'f32': F32, 'bf16x3': BF16X3, 'bf16': BF16, 'f16x3': F16X3}
-ABI_VERSION = 3   # VTC_ABI_VERSION of include/vtc_hip.h this binding matches
+ABI_VERSION = 4   # VTC_ABI_VERSION of include/vtc_hip.h this binding matches
 
 _lib = None
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     'vtc_version': (ctypes.c_char_p, []),
     'vtc_last_error': (ctypes.c_char_p, []),
     'vtc_abi_version': (_i32, []),
+    'vtc_init': (_i32, []),
     'vtc_gram': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'vtc_lambda_max_workspace_bytes': (_sz, [_i64]),
     'vtc_lambda_max': (_i32, [_vp, _i64, _vp, _vp, _sz, _vp]),
@@ -148,6 +149,23 @@ def load_library():
     raise ImportError('libvtc_hip.so ABI version mismatch')
   _lib = lib
   return lib
+
+
+_prepared_devices = set()
+
+
+def prepare_device(device):
+  """vtc_init() on `device`, once per process: the library's per-device
+  constants (the FISTA momentum table) are placed before the first inference
+  call is enqueued there."""
+  index = torch.device(device).index
+  if index is None:
+    index = torch.cuda.current_device()
+  if index in _prepared_devices:
+    return
+  with torch.cuda.device(index):
+    check(load_library().vtc_init(), 'vtc_init')
+  _prepared_devices.add(index)
 
 
 def check(status, what):
@@ -298,16 +316,29 @@ def poll_spectrum_checks(block=False):
     if not (lam == lam) or lam in (float('inf'), float('-inf')):
       del _pending_spectra[:]
       _report_bad_spectrum(dictionary)
+    if float(pinned[2]) != 1.0:
+      del _pending_spectra[:]
+      _report_unconverged(lam)
+
+
+def _report_unconverged(lam):
+  """The reference's symeig is exact; a Lanczos run that was still moving when
+  it hit its step limit may sit BELOW lambda_max, i.e. give a step size above
+  1 / L.  Treated like a failed eigen-solve (vtc_lambda_max's third output)."""
+  raise RuntimeError(
+      'the Lanczos eigen-solve had not converged at its step limit (top Ritz '
+      'value %r still moving by more than 1e-7 per 8 steps)' % lam)
 
 
 def lambda_max_device(gram_matrix, host_mirror=None):
   """[lambda_max, 1 / lambda_max] of a symmetric (n, n) device matrix,
-  n <= 1024, as a 2-element device tensor (vtc_lambda_max: one small HIP
-  kernel, Lanczos + Sturm counts).  host_mirror: optional pinned CPU tensor of
-  2 floats the kernel writes the same values through."""
+  n <= 1024, and the convergence flag of the solve, as a 3-element device
+  tensor (vtc_lambda_max: one small HIP kernel, Lanczos + Sturm counts).
+  host_mirror: optional pinned CPU tensor of 3 floats the kernel writes the
+  same values through."""
   lib = load_library()
   n = gram_matrix.shape[0]
-  out = torch.empty(2, dtype=torch.float32, device=gram_matrix.device)
+  out = torch.empty(3, dtype=torch.float32, device=gram_matrix.device)
   ws = workspace(lib.vtc_lambda_max_workspace_bytes(n), gram_matrix.device)
   check(lib.vtc_lambda_max_mirrored(
       ptr(gram_matrix), n, ptr(out),
@@ -328,7 +359,7 @@ def stepsize_on_device(gram_matrix, dictionary_for_message):
   poll_spectrum_checks()
   pinned = None
   if spectrum_check:
-    pinned = torch.empty(2, dtype=torch.float32, pin_memory=True)
+    pinned = torch.empty(3, dtype=torch.float32, pin_memory=True)
   out = lambda_max_device(gram_matrix, pinned)
   if spectrum_check:
     event = torch.cuda.Event()
@@ -348,15 +379,23 @@ def stepsize_from_gram(gram_matrix, dictionary_for_message):
   on failure print the kernel norms and raise a bare RuntimeError
   (ista_fista.py:75-79)."""
   n = gram_matrix.shape[0]
+  unconverged = None
   try:
     if device_stepsize_available(n):
       out = lambda_max_device(gram_matrix)
-      lipschitz_constant, stepsize = [float(v) for v in out.tolist()]
+      lipschitz_constant, stepsize, converged = [
+          float(v) for v in out.tolist()]
       if not (lipschitz_constant == lipschitz_constant) or (
           lipschitz_constant in (float('inf'), float('-inf'))):
         raise RuntimeError('non-finite spectrum')
-      return stepsize
-    lipschitz_constant = torch.linalg.eigvalsh(gram_matrix, UPLO='U')[-1]
+      if converged != 1.0:
+        unconverged = lipschitz_constant
+      else:
+        return stepsize
+    if unconverged is None:
+      lipschitz_constant = torch.linalg.eigvalsh(gram_matrix, UPLO='U')[-1]
   except RuntimeError:
     _report_bad_spectrum(dictionary_for_message)
+  if unconverged is not None:
+    _report_unconverged(unconverged)
   return float(1. / lipschitz_constant)

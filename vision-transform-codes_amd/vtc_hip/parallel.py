@@ -19,6 +19,13 @@ _enabled = False
 _equal_shards = True
 _deferred = []      # [(tensor, callback)] riding on the next all_reduce_sum_
 collectives_issued = 0   # all-reduce calls so far (tests count them)
+packed_copies = 0        # all-reduces that had to pack their tensors first
+# One persistent flat float32 buffer per device: `take` hands out consecutive
+# slices of it (the code energy, then the gradient), so that the all-reduce of
+# an update step sums one contiguous range in place -- no torch.cat, no copy
+# back, no allocation per step.
+_flat = {}          # device -> [flat tensor, cursor]
+_ALIGN = 64         # elements (256 bytes) between slices
 
 
 def enable(group=None, equal_shards=True):
@@ -38,6 +45,65 @@ def disable():
   global _group, _enabled
   _group, _enabled = None, False
   del _deferred[:]
+  _flat.clear()
+
+
+def take(shape, device):
+  """A float32 tensor of `shape` for a quantity that will be summed over
+  ranks.  Data parallel: the next slice of the device's persistent flat
+  buffer (released again by the all-reduce that consumes it); otherwise a
+  plain allocation."""
+  device = torch.device(device)
+  count = 1
+  for extent in shape:
+    count *= int(extent)
+  if not is_enabled():
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+  entry = _flat.get(device)
+  padded = (count + _ALIGN - 1) // _ALIGN * _ALIGN
+  if entry is None or entry[1] + padded > entry[0].numel():
+    # first use, or outgrown: slices handed out earlier stay valid (they keep
+    # the old storage alive) and that one step packs with a copy
+    size = max(2 * padded + (entry[1] if entry else 0), 1 << 18)
+    entry = _flat[device] = [
+        torch.zeros(size, dtype=torch.float32, device=device), 0]
+  flat, cursor = entry
+  entry[1] = cursor + padded
+  return flat[cursor: cursor + count].view(tuple(shape))
+
+
+def _contiguous_range(tensors):
+  """(flat, start, end) when every tensor is a slice of one persistent flat
+  buffer and together (with their alignment gaps) they cover [start, end);
+  None otherwise."""
+  if not tensors:
+    return None
+  entry = _flat.get(tensors[0].device)
+  if entry is None:
+    return None
+  flat = entry[0]
+  base = flat.data_ptr()
+  spans = []
+  for t in tensors:
+    if (t.dtype != torch.float32 or not t.is_contiguous() or
+        t.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr()):
+      return None
+    first = (t.data_ptr() - base) // 4
+    spans.append((first, first + t.numel()))
+  spans.sort()
+  for (_, end), (start, _) in zip(spans, spans[1:]):
+    if start < end or start - end >= _ALIGN:
+      return None
+  return flat, spans[0][0], spans[-1][1]
+
+
+def drop_deferred():
+  """Forget what `defer` queued and release the flat buffer's slices: called
+  when an update plugin raised between defer() and its all-reduce, so that the
+  next step does not reduce a different element count than the other ranks."""
+  del _deferred[:]
+  for entry in _flat.values():
+    entry[1] = 0
 
 
 def is_enabled():
@@ -99,9 +165,17 @@ def all_reduce_sum_(*tensors):
   if not everything:
     return
   collectives_issued += 1
-  if len(everything) == 1:
+  in_place = _contiguous_range(everything)
+  for entry in _flat.values():
+    entry[1] = 0           # the slices handed out so far are consumed
+  if in_place is not None:
+    flat, start, end = in_place
+    dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=_group)
+  elif len(everything) == 1:
     dist.all_reduce(everything[0], op=dist.ReduceOp.SUM, group=_group)
   else:
+    global packed_copies
+    packed_copies += 1
     flat = torch.cat([t.reshape(-1) for t in everything])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=_group)
     offset = 0
@@ -110,3 +184,37 @@ def all_reduce_sum_(*tensors):
       offset += t.numel()
   for _, callback in pending:
     callback()
+
+
+def broadcast_reset_or_prune(dictionary, affected, groups):
+  """Make every rank adopt rank 0's reset / prune decision
+  (training/sparse_coding.py: dict_element_rp_schedule under data parallelism:
+  the selection draws from each process's own numpy / torch CPU generators, so
+  only rank 0's draw counts).
+
+  dictionary: rank 0: the tensor reset_or_prune_dict_elements returned; other
+  ranks: their current dictionary.  affected / groups: rank 0's results
+  (ignored elsewhere).  Returns (dictionary, affected, groups) identical on
+  all ranks: after a reset the caller's tensor, overwritten in place; after a
+  prune a tensor of rank 0's new shape."""
+  if not is_enabled():
+    return dictionary, affected, groups
+  header = [None]
+  if rank() == 0:
+    header = [(tuple(dictionary.shape),
+               [int(a) for a in torch.as_tensor(affected).reshape(-1).tolist()]
+               if len(affected) else [], groups)]
+  dist.broadcast_object_list(header, src=0, group=_group)
+  shape, affected_list, groups0 = header[0]
+  if rank() != 0:
+    import numpy as np
+    affected = np.asarray(affected_list, dtype=np.int64)
+    if groups is not None and groups0 is not None:
+      groups[:] = groups0           # in place: the trainer aliases this list
+    if tuple(dictionary.shape) != tuple(shape):
+      dictionary = torch.empty(shape, dtype=dictionary.dtype,
+                               device=dictionary.device)
+  if not dictionary.is_contiguous():
+    dictionary = dictionary.contiguous()
+  dist.broadcast(dictionary, src=0, group=_group)
+  return dictionary, affected, groups
