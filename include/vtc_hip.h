@@ -78,8 +78,9 @@ enum vtc_precision {
   VTC_BF16 = 2,   /* single bf16 MFMA product, f32 accumulate: fast mode     */
   VTC_F16X3 = 3   /* f16 hi/lo split (11 + 11 bits) in power-of-two scaled
                    * units, 3 MFMA products: ~2^-21 per product at the bf16x3
-                   * cost.  Fused fully-connected kernel only; elsewhere it
-                   * runs as VTC_BF16X3.                                      */
+                   * cost.  Fused fully-connected kernels and the convolutional
+                   * inference; the tiled contractions and the convolutional
+                   * dictionary gradient run it as VTC_BF16X3.                */
 };
 
 const char* vtc_version(void);
@@ -105,8 +106,8 @@ int vtc_gram(const float* a, int64_t rows, int64_t cols, int transpose_a,
  * + Sturm counts.  out (device, 3 floats) = [lambda_max, 1/lambda_max,
  * converged].  A Ritz value approaches lambda_max from below, so the kernel
  * checks itself: the top Ritz value of all steps against that of the steps up
- * to 8 earlier, going on (n <= 256: up to min(2n, 256) steps) while they differ
- * by more than 1e-7 relative; converged = 1.0 when they agree or the Krylov
+ * to 8 earlier, going on (n <= 256: up to min(max(2n, n + 48), 256) steps) while they differ
+ * by more than 1e-6 relative; converged = 1.0 when they agree or the Krylov
  * space is exhausted, 0.0 when the step limit ended the iteration -- the
  * reference's symeig is exact (ista_fista.py:72-80), a caller should treat 0
  * like its failure.  n <= 256 needs no workspace (NULL, 0); 256 < n <= 1024
@@ -206,10 +207,11 @@ size_t vtc_conv_ista_fista_workspace_bytes(const vtc_conv_geometry* g);
  * kernels of 5, 8, 11 or 16, operand planes within the 160 KiB LDS. */
 int vtc_conv_x3_supported(const vtc_conv_geometry* g);
 /* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w).
- * precision: VTC_F32 (direct f32 convolutions, fixed summation order) or
- * VTC_BF16X3 (both convolutions as bf16 hi/lo split MFMA contractions;
+ * precision: VTC_F32 (direct f32 convolutions, fixed summation order),
+ * VTC_F16X3 or VTC_BF16X3 (both convolutions as hi/lo split MFMA
+ * contractions, f16 in power-of-two scaled units or bf16;
  * VTC_ERR_UNSUPPORTED unless vtc_conv_x3_supported).  With kernels up to
- * 11x11 and more than 32 of them VTC_BF16X3 runs one fused launch per
+ * 11x11 and more than 32 of them the split modes run one fused launch per
  * iteration (analysis, proximal step and the next residual) on code maps kept
  * in an internal tile order; the caller's layout is written by the last one. */
 int vtc_conv_ista_fista(const float* images_padded, const float* dictionary,

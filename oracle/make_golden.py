@@ -370,6 +370,66 @@ def make_conv(ref):
   np.savez_compressed(GOLDEN / 'conv.npz', **out)
 
 
+def near_delta_kernels(seed, s, k, eps):
+  """Unit-norm kernels that are a centred delta plus eps * N(0,1): nearly
+  parallel as vectors (lambda_max(F F^T) ~ s) and nearly white as filters, so
+  that the reference's own step 1 / lambda_max(F F^T)
+  (convolutional/ista_fista.py:104-113) is a valid step for a STRIDE-1
+  convolution and the iteration converges.  (With random kernels that estimate
+  is far below the operator norm and the iterates grow geometrically.)"""
+  rs = np.random.RandomState(seed)
+  d = (eps * rs.randn(s, 1, k, k)).astype(np.float32)
+  d[:, 0, k // 2, k // 2] += 1.0
+  nrm = np.sqrt((d.astype(np.float64)**2).sum(axis=(1, 2, 3))).astype(
+      np.float32)
+  return (d / nrm[:, None, None, None]).astype(np.float32)
+
+
+def make_conv_long(ref):
+  """Long-horizon convolutional traces (T = 10, 50, 100, FISTA, the
+  reference's own step size): the reference's example geometry -- 64 kernels
+  of 16x16, stride 8 (vtc/examples/train_convolutional_sparse_coding.py:39,
+  vtc/tests/ista_fista_2.py:16-24), whose iterates GROW with random kernels
+  (4.8e27 at T = 100, still finite in float32) -- and a convergent stride-1
+  11x11 case with 64 near-delta kernels (the geometry class of BASELINE
+  configs[4], on the fused matrix-core kernel)."""
+  out = {}
+  lam = 0.05
+  cases = {
+      'ex_k16s8': dict(img=64, k=16, stride=8, s=64, b=2, seed=40,
+                       kernels=lambda: unit_kernels(41, 64, 1, 16, 16)),
+      'nd_k11s1': dict(img=40, k=11, stride=1, s=64, b=2, seed=44,
+                       kernels=lambda: near_delta_kernels(45, 64, 11, 0.02)),
+  }
+  for name, g in cases.items():
+    lead, trail = ref.conv_utils.get_padding_amt(g['img'], g['k'], g['stride'])
+    padded = g['img'] + lead + trail
+    rs = np.random.RandomState(g['seed'])
+    imgs = np.zeros((g['b'], 1, padded, padded), np.float32)
+    imgs[:, :, lead:lead + g['img'], lead:lead + g['img']] = (
+        0.5 * rs.randn(g['b'], 1, g['img'], g['img'])).astype(np.float32)
+    D = g['kernels']()
+    stride = (g['stride'], g['stride'])
+    pad = ((lead, trail), (lead, trail))
+    out[name + '_images_padded'] = imgs
+    out[name + '_dictionary'] = D
+    out[name + '_stride'] = np.array(stride)
+    out[name + '_padding'] = np.array(pad)
+    F = T(D.reshape(D.shape[0], -1))
+    out[name + '_stepsize'] = np.float32(
+        1. / torch.linalg.eigvalsh(torch.mm(F, F.t()), UPLO='U')[-1])
+    for iters in (10, 50, 100):
+      codes = ref.conv_inf.run(T(imgs), T(D), stride, pad, lam, iters,
+                               variant='fista')
+      assert bool(torch.isfinite(codes).all())
+      report('conv_long %s fista T=%d' % (name, iters),
+             sc_oracle.conv_ista_fista(T(imgs), T(D), stride, pad, lam, iters,
+                                       variant='fista'), codes)
+      out['%s_codes_fista_T%d' % (name, iters)] = codes.numpy()
+  out['sparsity_weight'] = np.float32(lam)
+  np.savez_compressed(GOLDEN / 'conv_long.npz', **out)
+
+
 class _ListDataset(torch.utils.data.Dataset):
   def __init__(self, tensor):
     self.tensor = tensor
@@ -745,6 +805,7 @@ def make_whitened(ref):
 
 MAKERS = {'fc_c1': make_fc_c1, 'fc_c2_mini': make_fc_c2_mini,
           'subspace': make_subspace, 'conv': make_conv,
+          'conv_long': make_conv_long,
           'trainer': make_trainer, 'trainer_c2': make_trainer_c2, 'reset_prune': make_reset_prune,
           'whitened': make_whitened,
           'metrics': make_metrics, 'ica': make_ica}

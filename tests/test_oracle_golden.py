@@ -166,6 +166,25 @@ def test_conv_golden_and_index_conventions():
     assert helpers.rel_err(Dn.numpy(), g[name + '_dict_after_cheapquad']) < 1e-6
 
 
+def test_conv_long_horizon_golden():
+  """The oracle follows the reference through 100 FISTA iterations on both
+  long-horizon cases (bit-identical when the fixture was written), and its
+  step size is the reference's."""
+  g = helpers.load('conv_long')
+  lam = float(g['sparsity_weight'])
+  for name in ('ex_k16s8', 'nd_k11s1'):
+    imgs, D = T(g[name + '_images_padded']), T(g[name + '_dictionary'])
+    stride = tuple(int(v) for v in g[name + '_stride'])
+    pad = tuple(tuple(int(v) for v in row) for row in g[name + '_padding'])
+    assert abs(float(sc_oracle.conv_stepsize(D)) -
+               float(g[name + '_stepsize'])) < 1e-7
+    for iters in (10, 100):
+      codes = sc_oracle.conv_ista_fista(imgs, D, stride, pad, lam, iters,
+                                        variant='fista')
+      assert helpers.rel_err(
+          codes.numpy(), g['%s_codes_fista_T%d' % (name, iters)]) < 1e-6
+
+
 def test_conv_geometry_matches_config5():
   # SURVEY.md section 8: 256 px, 11x11 kernels, stride 1 -> pad (10,10),
   # padded 276, code map 266

@@ -61,7 +61,7 @@ def conv(dev):
   X, D = torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev)
   padding = ((pad, pad), (pad, pad))
   flop_iter = 4.0 * s * k * k * 266 * 266
-  for prec in ('f32', 'bf16x3'):
+  for prec in ('f32', 'bf16x3', 'f16x3'):
     dt, codes = timed(lambda: ista_fista.run(X, D, (1, 1), padding, 0.02,
                                              iters, precision=prec))
     print('config 5 conv [%s]: b=%d  %d-iter conv FISTA  %.1f ms  = %.3f '

@@ -24,10 +24,12 @@ def run(images_padded, dictionary, kernel_stride, padding_dims,
   device.  kernel_stride (sv, sh); padding_dims ((lead_v, trail_v),
   (lead_h, trail_h)) or None.  Returns codes (b, s, code_h, code_w).
   Extensions: `stepsize` (skip the eigen-solve) and `precision` in {None,
-  'auto', 'f32', 'bf16x3'}.  'bf16x3' runs both convolutions as bf16 hi/lo
-  split contractions on the matrix cores (one channel, stride 1, square
-  kernels of 5/8/11/16); 'auto' picks it where it applies and the direct f32
-  kernels elsewhere.
+  'auto', 'f32', 'f16x3', 'bf16x3'}.  The split modes run both convolutions as
+  hi/lo split contractions on the matrix cores (one channel, stride 1, square
+  kernels of 5/8/11/16): 'f16x3' in power-of-two scaled units with 11 + 11
+  significand bits (float32-level results: 4e-6 from the reference's codes at
+  T = 100, profiles/r03_precision_conv.txt), 'bf16x3' with 8 + 8 (1.8e-5).
+  'auto' picks f16x3 where it applies and the direct f32 kernels elsewhere.
   """
   assert variant in ['ista', 'fista']
   lib = vtc_hip.load_library()
@@ -69,9 +71,9 @@ def run(images_padded, dictionary, kernel_stride, padding_dims,
       vtc_hip.get_default_precision())
   if name == 'auto':
     # hard thresholds stay on the exact-f32 kernels: a discontinuous threshold
-    # turns the bf16x3 products' ~1e-5 differences into flips of the cutoff's
-    # size, which the split path is only pinned for over a single iteration
-    name = 'bf16x3' if (geom.s >= 32 and not hard_threshold and
+    # turns last-bit differences of the products into flips of the cutoff's
+    # size, which the split paths are only pinned for over a single iteration
+    name = 'f16x3' if (geom.s >= 32 and not hard_threshold and
                         lib.vtc_conv_x3_supported(ctypes.byref(geom))) else (
                             'f32')
   if name == 'bf16':

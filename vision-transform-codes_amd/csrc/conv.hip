@@ -452,6 +452,10 @@ static size_t conv_x3_image_bytes(const ConvGeo& g) {
   return cx_plan(g, &p) ? cx_image_bytes(p) + cx_fused_bytes(p) : 0;
 }
 
+// f16x3 scale state (conv_x3.h, CxScales): {sigma_D, 1 / sigma_D} and two
+// slots each for max |R| and max |Y|
+constexpr int kCxStateWords = 64 + 4 * kCxMaxSlotWords;
+
 static size_t conv_inference_ws(const ConvGeo& g) {
   const size_t code_elems = (size_t)g.b * g.s * g.ch * g.cw;
   const size_t img_elems = (size_t)g.b * g.c * g.H * g.W;
@@ -461,6 +465,7 @@ static size_t conv_inference_ws(const ConvGeo& g) {
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
          conv_x3_image_bytes(g) +                             // bf16x3 operands
          patch_workspace_bytes(g) +                           // im2col, Q
+         align_up(kCxStateWords * sizeof(unsigned), 256) +    // f16x3 scales
          256;
 }
 
@@ -521,15 +526,18 @@ extern "C" int vtc_conv_ista_fista(
     void* workspace, size_t workspace_bytes, int* iters_run, void* stream) {
   VTC_REQUIRE((geom && geom->b == 0) || (images_padded && dictionary && codes),
               "vtc_conv_ista_fista: null pointer");
-  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
-              "vtc_conv_ista_fista: precision must be VTC_F32 or VTC_BF16X3");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3 ||
+                  precision == VTC_F16X3,
+              "vtc_conv_ista_fista: precision must be VTC_F32, VTC_F16X3 or "
+              "VTC_BF16X3");
   ConvGeo g;
   int rc = make_geo(geom, &g);
   if (rc != VTC_OK) return rc;
   CxPlan xp;
-  const bool x3 = (precision == VTC_BF16X3);
+  const bool x3 = (precision == VTC_BF16X3 || precision == VTC_F16X3);
+  const bool f16 = (precision == VTC_F16X3);
   if (x3 && !cx_plan(g, &xp)) {
-    set_error("vtc_conv_ista_fista: bf16x3 covers one channel, stride 1 and "
+    set_error("vtc_conv_ista_fista: the split modes cover one channel, stride 1 and "
               "square kernels of 5, 8, 11 or 16 (see "
               "vtc_conv_x3_supported)");
     return VTC_ERR_UNSUPPORTED;
@@ -561,10 +569,29 @@ extern "C" int vtc_conv_ista_fista(
   float* partial = nullptr;
   float* Cfrag1 = nullptr;          // the last two code iterates of that
   float* Cfrag0 = nullptr;          // kernel, fragment order (CxMaps)
+  // f16x3: power-of-two scales of the operands (conv_x3.h, CxScales)
+  unsigned* state = ws.take<unsigned>(kCxStateWords);
+  float* dscale = f16 ? reinterpret_cast<float*>(state) : nullptr;
+  unsigned* r_slot[2] = {state + 64, state + 64 + kCxMaxSlotWords};
+  unsigned* y_slot[2] = {state + 64 + 2 * kCxMaxSlotWords,
+                         state + 64 + 3 * kCxMaxSlotWords};
+  if (f16) {
+    VTC_HIP_CHECK(hipMemsetAsync(state, 0, kCxStateWords * sizeof(unsigned),
+                                 st));
+    hipLaunchKernelGGL(cx_array_scale_kernel, dim3(1), dim3(1024), 0, st,
+                       dictionary, (int64_t)g.s * g.c * g.kh * g.kw, dscale);
+    VTC_LAUNCH_CHECK();
+    if (initial_codes) {
+      hipLaunchKernelGGL(cx_array_max_kernel, dim3(1024), dim3(256), 0, st,
+                         initial_codes,
+                         (int64_t)g.b * g.s * g.ch * g.cw, y_slot[0]);
+      VTC_LAUNCH_CHECK();
+    }
+  }
   if (x3) {
     syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
-    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
+    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, dscale, st);
     // fused iteration kernel (kernels up to 11x11, more than 32 of them)
     static const bool no_fused = getenv("VTC_CONV_NO_FUSED") != nullptr;
     if (rc == VTC_OK && xp.fused_lds != 0 && !no_fused) {
@@ -572,9 +599,14 @@ extern "C" int vtc_conv_ista_fista(
       partial = ws.take<float>(xp.partial_bytes / sizeof(float));
       Cfrag1 = ws.take<float>(xp.padded_bytes / sizeof(float));
       Cfrag0 = ws.take<float>(xp.padded_bytes / sizeof(float));
-      hipLaunchKernelGGL(conv_x3_pack_synp_kernel, dim3(256), dim3(256), 0, st,
-                         dictionary, synp_image, g.s, xp.k, xp.slots,
-                         xp.chunks);
+      if (f16)
+        hipLaunchKernelGGL(conv_x3_pack_synp_kernel<true>, dim3(256),
+                           dim3(256), 0, st, dictionary, synp_image, g.s, xp.k,
+                           xp.slots, xp.chunks, dscale);
+      else
+        hipLaunchKernelGGL(conv_x3_pack_synp_kernel<false>, dim3(256),
+                           dim3(256), 0, st, dictionary, synp_image, g.s, xp.k,
+                           xp.slots, xp.chunks, dscale);
       VTC_LAUNCH_CHECK();
     }
     if (rc != VTC_OK) return rc;
@@ -642,8 +674,10 @@ extern "C" int vtc_conv_ista_fista(
       // order (conv_x3.h, CxMaps; Y is recomputed from them); the last launch
       // writes the codes in the caller's layout.
       if (k == 0) {
+        CxScales first{dscale, nullptr, r_slot[0], nullptr, y_slot[0], nullptr,
+                       nullptr};
         rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
-                             st);
+                             first, st);
         if (rc != VTC_OK) return rc;
         VTC_HIP_CHECK(hipMemsetAsync(Cfrag1, 0, xp.padded_bytes, st));
         VTC_HIP_CHECK(hipMemsetAsync(Cfrag0, 0, xp.padded_bytes, st));
@@ -665,15 +699,28 @@ extern "C" int vtc_conv_ista_fista(
       maps.old = (k & 1) ? Cfrag0 : Cfrag1;          // c_(k-1) in, c_(k+1) out
       maps.user_codes = last ? codes : nullptr;
       maps.beta_prev = (fista && k > 0) ? betas[k - 1] : 0.f;
+      // the launch reads max |R_k| and clears the slot into which the
+      // residual kernel behind it leaves max |R_(k+1)|
+      CxScales sc{dscale, r_slot[k & 1], r_slot[(k + 1) & 1],
+                  r_slot[(k + 1) & 1], nullptr, nullptr, nullptr};
       rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
                            images_padded, residual, g, xp, pp,
-                           k + 1 < num_iters, st);
+                           k + 1 < num_iters, sc, st);
       if (rc != VTC_OK) return rc;
       frag_latest = maps.old;
     } else if (x3) {
-      rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp, st);
+      // synthesis: reads max |Y_k|, leaves max |R_k|, clears the slot of
+      // max |Y_(k+1)|; analysis: reads max |R_k|, leaves max |Y_(k+1)|, clears
+      // the slot of max |R_(k+1)|
+      CxScales syn_sc{dscale, nullptr, r_slot[k & 1], nullptr, y_slot[k & 1],
+                      nullptr, y_slot[(k + 1) & 1]};
+      rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp,
+                           syn_sc, st);
       if (rc != VTC_OK) return rc;
-      rc = cx_launch_analysis(residual, ana_image, Y, Cin, g, xp, pp, st);
+      CxScales ana_sc{dscale, r_slot[k & 1], nullptr, r_slot[(k + 1) & 1],
+                      nullptr, y_slot[(k + 1) & 1], nullptr};
+      rc = cx_launch_analysis(residual, ana_image, Y, Cin, g, xp, pp, ana_sc,
+                              st);
       if (rc != VTC_OK) return rc;
     } else if (patch_path) {
       // strides > 1: both convolutions as exact-f32 patch contractions
@@ -772,15 +819,16 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
                                       size_t workspace_bytes, void* stream) {
   VTC_REQUIRE(images_padded && dictionary && codes && grad_sum,
               "vtc_conv_dict_gradient: null pointer");
-  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3,
-              "vtc_conv_dict_gradient: precision must be VTC_F32 or "
-              "VTC_BF16X3");
+  VTC_REQUIRE(precision == VTC_F32 || precision == VTC_BF16X3 ||
+                  precision == VTC_F16X3,
+              "vtc_conv_dict_gradient: precision must be VTC_F32, VTC_F16X3 "
+              "or VTC_BF16X3");
   ConvGeo g;
   int rc = make_geo(geom, &g);
   if (rc != VTC_OK) return rc;
   VTC_REQUIRE(g.b > 0, "vtc_conv_dict_gradient: empty batch");
   CxPlan xp;
-  const bool x3 = (precision == VTC_BF16X3);
+  const bool x3 = (precision == VTC_BF16X3 || precision == VTC_F16X3);
   if (x3 && !cx_plan(g, &xp)) {
     set_error("vtc_conv_dict_gradient: no bf16x3 route for this geometry "
               "(see vtc_conv_x3_supported)");
@@ -809,9 +857,14 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
                                    dict_elems);
     uint16_t* syn_image = ws.take<uint16_t>(xp.syn_image_bytes / 2);
     uint16_t* ana_image = ws.take<uint16_t>(xp.ana_image_bytes / 2);
-    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, st);
+    // (the gradient stays on the bf16 split: a single product, no iteration
+    // to amplify its 2^-17, and its tests hold 5e-6 on the updated kernels)
+    const CxScales none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr};
+    rc = cx_pack(dictionary, g, xp, syn_image, ana_image, nullptr, st);
     if (rc != VTC_OK) return rc;
-    rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp, st);
+    rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
+                         none, st);
     if (rc != VTC_OK) return rc;
     rc = cx_launch_grad(residual, codes, xslabs, g, xp, st);
     if (rc != VTC_OK) return rc;

@@ -77,13 +77,160 @@ __device__ __forceinline__ uint16_t cx_bits(__bf16 v) {
   return __builtin_bit_cast(uint16_t, v);
 }
 
+// ------------------------------------------------ operand types and scales
+// Two 16-bit operand types behind one template flag.  F16 = false: bf16 hi/lo
+// (8 + 8 significand bits, 2^-17 per product: 1.6e-5 from the reference after
+// 200 iterations).  F16 = true: f16 hi/lo (11 + 11 bits, 2^-22 per product,
+// the float32 noise floor) at the same MFMA rate and the same bytes -- f16 has
+// 5 exponent bits, so every operand is brought to the range [16, 32) by a
+// power of two first (exact, and undone exactly on the f32 accumulators):
+//   * the kernels: one sigma_D per call (dictionary_scale_kernel);
+//   * the residual: one sigma_R per launch, from max |R| which the kernel that
+//     WROTE the residual left in device memory (CxScales);
+//   * the momentum iterate Y as the synthesis operand: in the fused kernel one
+//     sigma per code column, taken from the values themselves (the column is
+//     the N index of the product, so its scale factors out of the sum over
+//     atoms); in the stand-alone synthesis kernel one sigma_Y per launch, from
+//     max |Y| left by the kernel that wrote Y.
+// An entry 2^12 below the maximum of its operand still has all 22 bits; below
+// that the lo part goes subnormal and the absolute error stays at 2^-29 of the
+// maximum.
+typedef _Float16 cx_f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 cx_mfma(const uint4& a, const uint4& b,
+                                          const f32x16& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(
+        __builtin_bit_cast(cx_f16x8, a), __builtin_bit_cast(cx_f16x8, b), c, 0,
+        0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+      __builtin_bit_cast(cx_bf16x8, a), __builtin_bit_cast(cx_bf16x8, b), c, 0,
+      0, 0);
+}
+
+// one value -> its 16-bit hi and lo parts (bit patterns)
+template <bool F16>
+__device__ __forceinline__ void cx_split1(float v, uint16_t& hi, uint16_t& lo) {
+  if (F16) {
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)h));
+  } else {
+    const __bf16 h = (__bf16)v;
+    hi = cx_bits(h);
+    lo = cx_bits((__bf16)(v - (float)h));
+  }
+}
+
+// Slots in which a kernel leaves max |x| of what it wrote, for the kernel that
+// reads it next: 32 words 128 bytes apart per quantity (a block adds to word
+// blockIdx % 32, so that a few thousand atomics do not queue on one address),
+// bit patterns of non-negative floats (ordered like the floats, NaN on top).
+constexpr int kCxMaxWords = 32;
+constexpr int kCxMaxStride = 32;                  // words between two slots
+constexpr int kCxMaxSlotWords = kCxMaxWords * kCxMaxStride;
+
+struct CxScales {
+  const float* dscale;      // {sigma_D, 1 / sigma_D}; null: bf16 mode
+  const unsigned* r_in;     // max |R| of the residual this launch reads
+  unsigned* r_out;          // ... of the residual it writes
+  unsigned* r_zero;         // cleared by this launch (the next writer's slot)
+  const unsigned* y_in;     // the same for the momentum iterate Y
+  unsigned* y_out;
+  unsigned* y_zero;
+};
+
+// power of two that brings a maximum with these bits to [16, 32); 1 for zero,
+// subnormal or non-finite maxima
+__device__ __forceinline__ void cx_scale_of_bits(unsigned bits, float* s,
+                                                 float* inv) {
+  const int e = (int)((bits >> 23) & 0xffu);
+  int field = 258 - e;                            // 127 + 4 - (e - 127)
+  field = field < 2 ? 2 : (field > 252 ? 252 : field);
+  const bool usable = e > 0 && e < 255;
+  *s = usable ? __uint_as_float((unsigned)field << 23) : 1.f;
+  *inv = usable ? __uint_as_float((unsigned)(254 - field) << 23) : 1.f;
+}
+
+// every lane of the calling wave gets the maximum over the slot's words
+__device__ __forceinline__ unsigned cx_read_max(const unsigned* slot) {
+  const int lane = threadIdx.x & 63;
+  unsigned v = slot ? slot[(lane & (kCxMaxWords - 1)) * kCxMaxStride] : 0u;
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// block-wide maximum of m (>= 0) added to the slot; `red` = 16 words of LDS
+// nobody else uses around this call (the barriers are inside)
+__device__ __forceinline__ void cx_publish_max(float m, unsigned* slot,
+                                               unsigned* red) {
+  unsigned v = __float_as_uint(m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+  const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < waves; ++w) v = red[w] > v ? red[w] : v;
+    atomicMax(slot + (blockIdx.x & (kCxMaxWords - 1)) * kCxMaxStride, v);
+  }
+}
+
+__device__ __forceinline__ void cx_clear_slot(unsigned* slot) {
+  if (slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kCxMaxWords)
+    slot[threadIdx.x * kCxMaxStride] = 0u;
+}
+
+// {sigma, 1 / sigma} of a small array (the kernels): one block
+__global__ __launch_bounds__(1024) void cx_array_scale_kernel(
+    const float* __restrict__ x, int64_t count, float* __restrict__ scale) {
+  __shared__ unsigned red[16];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(x[i]));
+  unsigned v = __float_as_uint(m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) v = red[w] > v ? red[w] : v;
+    cx_scale_of_bits(v, scale, scale + 1);
+  }
+}
+
+// max |x| of a large array into a CxScales slot (warm start: the initial
+// codes are the first synthesis operand)
+__global__ __launch_bounds__(256) void cx_array_max_kernel(
+    const float* __restrict__ x, int64_t count, unsigned* __restrict__ slot) {
+  __shared__ unsigned red[16];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+  cx_publish_max(m, slot, red);
+}
+
 // ------------------------------------------------------------------ pack
 // syn image (uint16): [plane][slot][s16 + 8]      D[s][tap(slot)], k = s
 // ana image (uint16): [chunk][plane][dy][2][AC][8]  D[chunk*AC + a][dy][8 h + j]
+template <bool F16>
 __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
                                     uint16_t* __restrict__ syn,
                                     uint16_t* __restrict__ ana, int s, int k,
-                                    int s16, int slots, int AC, int chunks) {
+                                    int s16, int slots, int AC, int chunks,
+                                    const float* __restrict__ dscale) {
+  const float sigma = F16 ? dscale[0] : 1.f;
   const int taps = k * k;
   const int pitch = s16 + 8;
   const int64_t syn_plane = (int64_t)slots * pitch;
@@ -114,28 +261,42 @@ __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
       hi = ana + (int64_t)chunk * 2 * ana_plane + rem;
       lo = hi + ana_plane;
     }
-    const __bf16 h = (__bf16)v;
-    *hi = cx_bits(h);
-    *lo = cx_bits((__bf16)(v - (float)h));
+    cx_split1<F16>(v * sigma, *hi, *lo);
   }
 }
 
-// registers -> one MFMA operand pair
-__device__ __forceinline__ void cx_split8(const float (&v)[8], cx_bf16x8& hi,
-                                          cx_bf16x8& lo) {
+// registers (times a power-of-two scale) -> one MFMA operand pair
+template <bool F16>
+__device__ __forceinline__ void cx_split8(const float (&v)[8], float scale,
+                                          uint4& hi, uint4& lo) {
+  if (F16) {
+    cx_f16x8 h, l;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    hi[j] = (__bf16)v[j];
-    lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    for (int j = 0; j < 8; ++j) {
+      const float x = v[j] * scale;
+      h[j] = (_Float16)x;
+      l[j] = (_Float16)(x - (float)h[j]);
+    }
+    hi = __builtin_bit_cast(uint4, h);
+    lo = __builtin_bit_cast(uint4, l);
+  } else {
+    cx_bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      h[j] = (__bf16)v[j];
+      l[j] = (__bf16)(v[j] - (float)h[j]);
+    }
+    hi = __builtin_bit_cast(uint4, h);
+    lo = __builtin_bit_cast(uint4, l);
   }
 }
 
 // ------------------------------------------------------------- synthesis
-template <int K>
+template <int K, bool F16>
 __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     const float* __restrict__ Y, const uint16_t* __restrict__ syn_image,
     const float* __restrict__ X, float* __restrict__ R, ConvGeo g, int s16,
-    int tiles_x, int tiles_y, int rows_per_wave) {
+    int tiles_x, int tiles_y, int rows_per_wave, CxScales sc) {
   using Dm = CxDims<K>;
   constexpr int MT = Dm::MT, NI = Dm::NI, TW = Dm::TW, PW = Dm::PW;
   // tile height: the waves' code rows y0-(K-1) .. y0-(K-1)+8*rows-1 reach the
@@ -157,6 +318,15 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   // back: block L is on XCD L % 8, slots L / 8 walk the tiles of strip
   // (slot / tiles_y) * 8 + XCD.  (Measured before: 895 MB of HBM-side reads
   // per launch for 290 MB of code maps.)
+  // F16: Y enters as sigma_Y Y, the kernels as sigma_D D; the reconstruction
+  // comes back by 1 / (sigma_Y sigma_D) before the image is subtracted
+  float y_scale = 1.f, unscale = 1.f;
+  if (F16) {
+    float inv_y;
+    cx_scale_of_bits(cx_read_max(sc.y_in), &y_scale, &inv_y);
+    unscale = inv_y * sc.dscale[1];
+    cx_clear_slot(sc.y_zero);
+  }
   const int64_t strips = g.b * tiles_x;
   const int64_t slot = (int64_t)blockIdx.x >> 3;
   const int64_t strip = (slot / tiles_y) * 8 + (blockIdx.x & 7);
@@ -253,24 +423,20 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     for (int kk = 0; kk < kBatch; ++kk) {
       const int ks = bt * kBatch + kk;
       if (ks >= nks) break;
-      cx_bf16x8 bh[NI], bl[NI];
+      uint4 bh[NI], bl[NI];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) cx_split8(src[ni][kk], bh[ni], bl[ni]);
+      for (int ni = 0; ni < NI; ++ni)
+        cx_split8<F16>(src[ni][kk], y_scale, bh[ni], bl[ni]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int off = (32 * mt + l31) * pitch + ks * 16 + 8 * half;
-        const cx_bf16x8 ah = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
-        const cx_bf16x8 al = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+        const uint4 ah = *reinterpret_cast<const uint4*>(Dh + off);
+        const uint4 al = *reinterpret_cast<const uint4*>(Dl + off);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bh[ni], acc[mt][ni], 0, 0, 0);
-          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bl[ni], acc[mt][ni], 0, 0, 0);
-          acc[mt][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              al, bh[ni], acc[mt][ni], 0, 0, 0);
+          acc[mt][ni] = cx_mfma<F16>(ah, bh[ni], acc[mt][ni]);
+          acc[mt][ni] = cx_mfma<F16>(ah, bl[ni], acc[mt][ni]);
+          acc[mt][ni] = cx_mfma<F16>(al, bh[ni], acc[mt][ni]);
         }
       }
     }
@@ -343,6 +509,7 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     if (q + 1 < total) compute(q + 1, buf1);
   }
   __syncthreads();
+  float r_max = 0.f;
   for (int e = tid; e < TH * TW; e += 512) {
     const int py = e / TW, px = e % TW;
     const int y = y0 + py, x = x0 + px;
@@ -351,8 +518,15 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
 #pragma unroll
     for (int w = 1; w < kCxSynWaves; ++w)
       sum = add_rn(sum, priv[w * TH * PW + py * PW + px]);
+    if (F16) sum *= unscale;
     const int64_t i = (img * g.H + y) * (int64_t)g.W + x;
-    R[i] = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+    const float rv = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+    R[i] = rv;
+    r_max = fmaxf(r_max, fabsf(rv));
+  }
+  if (F16 && sc.r_out) {
+    __syncthreads();                               // priv is free now
+    cx_publish_max(r_max, sc.r_out, reinterpret_cast<unsigned*>(priv));
   }
 }
 
@@ -364,11 +538,11 @@ struct __attribute__((packed, aligned(2))) CxUnaligned16 {
 // MA: 32-atom tiles per block (atom chunk AC = 32 * MA).  FAST: the common
 // case (FISTA, soft threshold, no early stopping) with every option folded at
 // compile time; the other instantiation reads them from ProxParams.
-template <int MA, bool FAST>
+template <int MA, bool FAST, bool F16>
 __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
-    int tiles_u, int chunks, int ana_rows, ProxParams pp) {
+    int tiles_u, int chunks, int ana_rows, ProxParams pp, CxScales sc) {
   constexpr int AC = 32 * MA;
   extern __shared__ __attribute__((aligned(16))) char cx_lds[];
   char* lds = cx_lds;
@@ -387,6 +561,17 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   // chunk) share their boundary cache lines, because code rows are not
   // 128-byte aligned, so a band stays on one XCD: block L runs on XCD L % 8,
   // and slots L / 8 walk the tiles of band (slot / tiles_v) * 8 + XCD.
+  // F16: the window enters as sigma_R R, the kernels as sigma_D D; the
+  // gradient step takes eta / (sigma_R sigma_D) -- a power-of-two factor
+  // commutes with the rounding of eta * G
+  float r_scale = 1.f, eta = pp.eta;
+  if (F16) {
+    float inv_r;
+    cx_scale_of_bits(cx_read_max(sc.r_in), &r_scale, &inv_r);
+    eta = pp.eta * (inv_r * sc.dscale[1]);
+    cx_clear_slot(sc.r_zero);
+  }
+  float y_max = 0.f;                               // of the next iterate
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_v = slot % tiles_v;
   const int64_t band = (int64_t)(slot / tiles_v) * 8 + xcd;
@@ -406,9 +591,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
       const int y = u0 + ry, x = v0 + rx;
       const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
-      const __bf16 h = (__bf16)v;
-      Rh[e] = cx_bits(h);
-      Rl[e] = cx_bits((__bf16)(v - (float)h));
+      cx_split1<F16>(F16 ? v * r_scale : v, Rh[e], Rl[e]);
     }
   }
   __syncthreads();
@@ -474,17 +657,19 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2);
         const unsigned vo = rr < left ? lane_off : 0x80000000u;
-        const float p = sub_rn(yv[r], mul_rn(pp.eta, tile[r]));
+        const float p = sub_rn(yv[r], mul_rn(eta, tile[r]));
         const float c = FAST ? shrink(p, pp.cutoff, VTC_SOFT)
                              : shrink(p, pp.cutoff, pp.mode);
         float d;
         if (fista) {
           d = sub_rn(c, cv[r]);
-          __builtin_amdgcn_raw_buffer_store_b32(
-              __float_as_uint(add_rn(c, mul_rn(pp.beta, d))), yws, vo,
-              (unsigned)rr * map4, 0);
+          const float y1 = add_rn(c, mul_rn(pp.beta, d));
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y1), yws, vo,
+                                                (unsigned)rr * map4, 0);
+          if (F16) y_max = fmaxf(y_max, fabsf(y1));
         } else {
           d = sub_rn(c, yv[r]);
+          if (F16) y_max = fmaxf(y_max, fabsf(c));
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c), cws, vo,
                                               (unsigned)rr * map4, 0);
@@ -501,7 +686,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ma][ni][r] = 0.f;
     for (int dy = 0; dy < k; ++dy) {
-      cx_bf16x8 bh[2], bl[2];
+      uint4 bh[2], bl[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int off = (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
@@ -509,24 +694,19 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
             *reinterpret_cast<const CxUnaligned16*>(Rh + off);
         const CxUnaligned16 l =
             *reinterpret_cast<const CxUnaligned16*>(Rl + off);
-        bh[ni] = __builtin_bit_cast(cx_bf16x8, h);
-        bl[ni] = __builtin_bit_cast(cx_bf16x8, l);
+        bh[ni] = __builtin_bit_cast(uint4, h);
+        bl[ni] = __builtin_bit_cast(uint4, l);
       }
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma) {
         const int off = ((dy * 2 + half) * AC + 32 * ma + l31) * 8;
-        const cx_bf16x8 ah = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dh + off));
-        const cx_bf16x8 al = __builtin_bit_cast(
-            cx_bf16x8, *reinterpret_cast<const uint4*>(Dl + off));
+        const uint4 ah = *reinterpret_cast<const uint4*>(Dh + off);
+        const uint4 al = *reinterpret_cast<const uint4*>(Dl + off);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bh[ni], acc[ma][ni], 0, 0, 0);
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              ah, bl[ni], acc[ma][ni], 0, 0, 0);
-          acc[ma][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              al, bh[ni], acc[ma][ni], 0, 0, 0);
+          acc[ma][ni] = cx_mfma<F16>(ah, bh[ni], acc[ma][ni]);
+          acc[ma][ni] = cx_mfma<F16>(ah, bl[ni], acc[ma][ni]);
+          acc[ma][ni] = cx_mfma<F16>(al, bh[ni], acc[ma][ni]);
         }
       }
     }
@@ -552,6 +732,10 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   if (pp.delta_sum) {
     const double w = wave_sum(local);
     if ((tid & 63) == 0) atomicAdd(pp.delta_sum, w);
+  }
+  if (F16 && sc.y_out) {
+    __syncthreads();                               // the window is free now
+    cx_publish_max(y_max, sc.y_out, reinterpret_cast<unsigned*>(Rh));
   }
 }
 
@@ -623,9 +807,12 @@ struct CxFused {
 // synp image (uint16): [chunk][plane][slot][AC + 8]: element a of a slot row
 // holds D[chunk*64 + 32 (a>>5) + 16 ((a>>4)&1) + 4 ((a>>3)&1) + (a&3) +
 // 8 ((a>>2)&1)][tap(slot)] -- the k order of the accumulator layout.
+template <bool F16>
 __global__ void conv_x3_pack_synp_kernel(const float* __restrict__ D,
                                          uint16_t* __restrict__ synp, int s,
-                                         int k, int slots, int chunks) {
+                                         int k, int slots, int chunks,
+                                         const float* __restrict__ dscale) {
+  const float sigma = F16 ? dscale[0] : 1.f;
   const int taps = k * k;
   const int pitch = 64 + 8;
   const int64_t plane = (int64_t)slots * pitch;
@@ -643,10 +830,8 @@ __global__ void conv_x3_pack_synp_kernel(const float* __restrict__ D,
                        4 * ((a >> 3) & 1) + (j & 3) + 8 * (j >> 2);
       if (atom < s) v = D[(int64_t)atom * taps + t];
     }
-    const __bf16 h = (__bf16)v;
     uint16_t* hi = synp + (int64_t)chunk * 2 * plane + rem;
-    hi[0] = cx_bits(h);
-    hi[plane] = cx_bits((__bf16)(v - (float)h));
+    cx_split1<F16>(v * sigma, hi[0], hi[plane]);
   }
 }
 
@@ -692,13 +877,13 @@ static size_t cx_frag_floats(const ConvGeo& g, int chunks, int rows, int cols) {
 
 // RAGGED: the atom count is not a multiple of 64 (the last chunk is partial)
 // STAMP: per-section s_memtime sums (diagnostics, VTC_CONV_STAMPS=1)
-template <int K, bool RAGGED, bool STAMP>
+template <int K, bool RAGGED, bool STAMP, bool F16>
 __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     const uint16_t* __restrict__ synp_image, CxMaps M,
     float* __restrict__ partial, ConvGeo g, int tiles_v, int tiles_u,
     int chunks, ProxParams pp, int do_synth, unsigned frag_bytes,
-    unsigned long long* stamps) {
+    unsigned long long* stamps, CxScales sc) {
   using Dm = CxDims<K>;
   using F = CxFused<K>;
   constexpr int AC = F::AC, MT = Dm::MT, WP = F::WP, WPITCH = F::WIN_PITCH;
@@ -750,6 +935,18 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     it.img = band / tiles_u;
     return it;
   };
+  // F16 (see the top of the file): the residual windows enter as sigma_R R,
+  // the kernels as sigma_D D, and the gradient step takes
+  // eta / (sigma_R sigma_D); the new iterate enters the synthesis product
+  // scaled per code column and the tap sums are scaled back before the fold
+  float r_scale = 1.f, eta = pp.eta, inv_d = 1.f;
+  if (F16) {
+    float inv_r;
+    cx_scale_of_bits(cx_read_max(sc.r_in), &r_scale, &inv_r);
+    inv_d = sc.dscale[1];
+    eta = pp.eta * (inv_r * inv_d);
+    cx_clear_slot(sc.r_zero);
+  }
   CxItem cur = decode(rank);
   if (!cur.valid) return;                           // whole block
 
@@ -773,9 +970,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     for (int q = 0; q < F::WIN_REGS; ++q) {
       const int e = tid + 512 * q;
       if (e < F::WIN_ELEMS) {
-        const __bf16 h = (__bf16)wreg[q];
-        const uint16_t hb = cx_bits(h);
-        const uint16_t lb = cx_bits((__bf16)(wreg[q] - (float)h));
+        uint16_t hb, lb;
+        cx_split1<F16>(F16 ? wreg[q] * r_scale : wreg[q], hb, lb);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           // pixel x of a row sits at position x - c of copy c.  The first c
@@ -857,7 +1053,7 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
                           ? add_rn(cv[r], mul_rn(M.beta_prev,
                                                  sub_rn(cv[r], yv[r])))
                           : cv[r];
-      const float p = sub_rn(y, mul_rn(pp.eta, tile[r]));
+      const float p = sub_rn(y, mul_rn(eta, tile[r]));
       const float c = shrink(p, pp.cutoff, MODE);
       const float d = sub_rn(c, cv[r]);
       const float y1 = pp.beta != 0.f ? add_rn(c, mul_rn(pp.beta, d)) : c;
@@ -926,14 +1122,14 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   f32x16 Q[MT];
   // Q += D[chunk atoms of tile ma, taps]^T * Y' (Y' as the B operand).  The
   // LDS reads of operand tile mt+1 are issued before the products of tile mt.
-  auto synth_tile = [&](int ma, const f32x16& yn) {
+  auto synth_tile = [&](int ma, const f32x16& yn, float col_scale) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v8[j] = yn[8 * ks + j];
-      cx_bf16x8 bh, bl;
-      cx_split8(v8, bh, bl);
+      uint4 bh, bl;
+      cx_split8<F16>(v8, col_scale, bh, bl);
       const int base = l31 * F::SYN_PITCH + 32 * ma + 16 * ks + 8 * half;
       uint4 ah = *reinterpret_cast<const uint4*>(Sh + base);
       uint4 al = *reinterpret_cast<const uint4*>(Sl + base);
@@ -946,11 +1142,9 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
           al_n = *reinterpret_cast<const uint4*>(Sl + off);
         }
         __builtin_amdgcn_sched_barrier(0);           // keep the reads up here
-        const cx_bf16x8 a_h = __builtin_bit_cast(cx_bf16x8, ah);
-        const cx_bf16x8 a_l = __builtin_bit_cast(cx_bf16x8, al);
-        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, Q[mt], 0, 0, 0);
-        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, Q[mt], 0, 0, 0);
-        Q[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, Q[mt], 0, 0, 0);
+        Q[mt] = cx_mfma<F16>(ah, bh, Q[mt]);
+        Q[mt] = cx_mfma<F16>(ah, bl, Q[mt]);
+        Q[mt] = cx_mfma<F16>(al, bh, Q[mt]);
         __builtin_amdgcn_sched_barrier(0);
         ah = ah_n;
         al = al_n;
@@ -1050,18 +1244,12 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
         AnaOps nx = ops;
         if (dy + 1 < K) nx = ana_load(Wb, dy + 1);
         __builtin_amdgcn_sched_barrier(0);           // keep the reads up here
-        const cx_bf16x8 bh = __builtin_bit_cast(cx_bf16x8, ops.bh);
-        const cx_bf16x8 bl = __builtin_bit_cast(cx_bf16x8, ops.bl);
-        const cx_bf16x8 ah0 = __builtin_bit_cast(cx_bf16x8, ops.ah0);
-        const cx_bf16x8 al0 = __builtin_bit_cast(cx_bf16x8, ops.al0);
-        const cx_bf16x8 ah1 = __builtin_bit_cast(cx_bf16x8, ops.ah1);
-        const cx_bf16x8 al1 = __builtin_bit_cast(cx_bf16x8, ops.al1);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh, acc[1], 0, 0, 0);
+        acc[0] = cx_mfma<F16>(ops.ah0, ops.bh, acc[0]);
+        acc[1] = cx_mfma<F16>(ops.ah1, ops.bh, acc[1]);
+        acc[0] = cx_mfma<F16>(ops.ah0, ops.bl, acc[0]);
+        acc[1] = cx_mfma<F16>(ops.ah1, ops.bl, acc[1]);
+        acc[0] = cx_mfma<F16>(ops.al0, ops.bh, acc[0]);
+        acc[1] = cx_mfma<F16>(ops.al1, ops.bh, acc[1]);
         __builtin_amdgcn_sched_barrier(0);
         ops = nx;
       }
@@ -1079,8 +1267,21 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       // then stores, then the loads of the next item into the freed registers
       // (most of an item of work between their issue and their use).
       prox_tile(cur, 0, yA, cA, acc[0]);
-      if (do_synth) synth_tile(0, acc[0]);
+      if (do_synth && !F16) synth_tile(0, acc[0], 1.f);
       prox_tile(cur, 1, yB, cB, acc[1]);
+      // F16: one power of two per code column (= lane, both halves) from the
+      // 64 values of the column this wave holds
+      float col_scale = 1.f, col_unscale = 1.f;
+      if (F16 && do_synth) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          m = fmaxf(m, fmaxf(fabsf(acc[0][r]), fabsf(acc[1][r])));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        cx_scale_of_bits(__float_as_uint(m), &col_scale, &col_unscale);
+        col_unscale *= inv_d;
+        synth_tile(0, acc[0], col_scale);
+      }
       if (pp.delta_sum) {
         const double w = wave_sum((double)stop_sum);
         if (lane == 0) atomicAdd(pp.delta_sum, w);
@@ -1093,7 +1294,13 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       load_tile(nxt, 0, yA, cA);
       load_tile(nxt, 1, yB, cB);
       stamp(8);
-      if (do_synth) synth_tile(1, acc[1]);
+      if (do_synth) synth_tile(1, acc[1], col_scale);
+      if (F16 && do_synth) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Q[mt][r] *= col_unscale;
+      }
       stamp(3);
       if (do_synth) fold(Priv + (buf * F::ROWS + wave) * K * WP);
       stamp(4);
@@ -1195,13 +1402,16 @@ __global__ void conv_from_fragments_kernel(const float* __restrict__ src,
 }
 
 // residual = mask * (sum of the partial tiles covering the pixel - image)
+// r_max_out (may be null): the slot that receives max |R| (CxScales)
 template <int K>
 __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
                                            const float* __restrict__ X,
                                            float* __restrict__ R, ConvGeo g,
                                            int tiles_v, int tiles_u,
-                                           int chunks) {
+                                           int chunks, unsigned* r_max_out) {
   using F = CxFused<K>;
+  __shared__ unsigned red[16];
+  float r_max = 0.f;
   const int64_t total = g.b * (int64_t)g.H * g.W;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -1236,8 +1446,11 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
           sum = add_rn(sum, tile[(y - tu * F::ROWS) * F::TW +
                                  (x - tv * F::COLS)]);
         }
-    R[i] = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+    const float rv = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
+    R[i] = rv;
+    r_max = fmaxf(r_max, fabsf(rv));
   }
+  if (r_max_out) cx_publish_max(r_max, r_max_out, red);
 }
 
 // ---------------------------------------------- dictionary gradient (a8/a9)
@@ -1341,8 +1554,8 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
             a[4 + i] = (v + 4 + i < g.cw) ? __uint_as_float(hi4[i]) : 0.f;
           }
         }
-        cx_bf16x8 ah, al;
-        cx_split8(a, ah, al);
+        uint4 ah, al;
+        cx_split8<false>(a, 1.f, ah, al);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const uint16_t* bp = Wc + 8 + (dx & 3) * COPY +
@@ -1352,16 +1565,11 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
           const uint2 h1 = *reinterpret_cast<const uint2*>(bp + 4);
           const uint2 l0 = *reinterpret_cast<const uint2*>(bp + PLANE);
           const uint2 l1 = *reinterpret_cast<const uint2*>(bp + PLANE + 4);
-          const cx_bf16x8 bh = __builtin_bit_cast(
-              cx_bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-          const cx_bf16x8 bl = __builtin_bit_cast(
-              cx_bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt],
-                                                            0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt],
-                                                            0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt],
-                                                            0, 0, 0);
+          const uint4 bh = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          const uint4 bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+          acc[nt] = cx_mfma<false>(ah, bh, acc[nt]);
+          acc[nt] = cx_mfma<false>(ah, bl, acc[nt]);
+          acc[nt] = cx_mfma<false>(al, bh, acc[nt]);
         }
       }
     }
@@ -1508,23 +1716,25 @@ static size_t cx_fused_bytes(const CxPlan& p) {
          2 * align_up(p.padded_bytes, 256);
 }
 
-template <int K, bool RAGGED>
+template <int K, bool RAGGED, bool F16>
 static int cx_launch_fused_k(const float* R, const uint16_t* ana,
                              const uint16_t* synp, const CxMaps& maps,
                              float* partial, const float* X, float* R_next,
                              const ConvGeo& g, const CxPlan& p,
                              const ProxParams& pp, bool do_synth,
-                             hipStream_t st) {
+                             const CxScales& sc, hipStream_t st) {
   using F = CxFused<K>;
   const int tiles_v = (int)ceil_div(g.cw, F::COLS);
   const int tiles_u = (int)ceil_div(g.ch, F::ROWS);
   static unsigned long long attr_set = 0;
   if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_fused_x3_kernel<K, RAGGED, false>),
+        reinterpret_cast<const void*>(
+            conv_fused_x3_kernel<K, RAGGED, false, F16>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_fused_x3_kernel<K, RAGGED, true>),
+        reinterpret_cast<const void*>(
+            conv_fused_x3_kernel<K, RAGGED, true, F16>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   // persistent blocks, one per CU: the same number for every (XCD, chunk)
@@ -1541,15 +1751,17 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
     VTC_HIP_CHECK(hipMemsetAsync(stamps_dev, 0, 80, st));
   }
   if (stamps_dev)
-    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, true>),
+    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, true, F16>),
                        dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
                        synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
-                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, stamps_dev);
+                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, stamps_dev,
+                       sc);
   else
-    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, false>),
+    hipLaunchKernelGGL((conv_fused_x3_kernel<K, RAGGED, false, F16>),
                        dim3((unsigned)blocks), dim3(512), F::lds, st, R, ana,
                        synp, maps, partial, g, tiles_v, tiles_u, p.chunks, pp,
-                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, nullptr);
+                       do_synth ? 1 : 0, (unsigned)p.padded_bytes, nullptr,
+                       sc);
   VTC_LAUNCH_CHECK();
   if (stamps_dev) {
     unsigned long long host[10];
@@ -1570,56 +1782,69 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
     if (rblocks > 65535) rblocks = 65535;
     hipLaunchKernelGGL(conv_partial_reduce_kernel<K>, dim3((unsigned)rblocks),
                        dim3(256), 0, st, partial, X, R_next, g, tiles_v,
-                       tiles_u, p.chunks);
+                       tiles_u, p.chunks, F16 ? sc.r_out : nullptr);
     VTC_LAUNCH_CHECK();
   }
   return VTC_OK;
 }
 
 // one fused iteration: (R, Y, C) -> (Y', C'), and R' unless it is the last one
+// sc.dscale != null selects the f16 split (CxScales)
 static int cx_launch_fused(const float* R, const uint16_t* ana,
                            const uint16_t* synp, const CxMaps& maps,
                            float* partial, const float* X, float* R_next,
                            const ConvGeo& g, const CxPlan& p,
                            const ProxParams& pp, bool do_synth,
-                           hipStream_t st) {
+                           const CxScales& sc, hipStream_t st) {
+  const bool f16 = sc.dscale != nullptr;
+#define VTC_CX_FUSED_T(KK, RG)                                                 \
+  (f16 ? cx_launch_fused_k<KK, RG, true>(R, ana, synp, maps, partial, X,       \
+                                         R_next, g, p, pp, do_synth, sc, st)   \
+       : cx_launch_fused_k<KK, RG, false>(R, ana, synp, maps, partial, X,      \
+                                          R_next, g, p, pp, do_synth, sc, st))
 #define VTC_CX_FUSED(KK)                                                       \
   case KK:                                                                     \
-    return (g.s % 64) ? cx_launch_fused_k<KK, true>(R, ana, synp, maps,        \
-                                                    partial, X, R_next, g, p,  \
-                                                    pp, do_synth, st)          \
-                      : cx_launch_fused_k<KK, false>(R, ana, synp, maps,       \
-                                                     partial, X, R_next, g, p, \
-                                                     pp, do_synth, st)
+    return (g.s % 64) ? VTC_CX_FUSED_T(KK, true) : VTC_CX_FUSED_T(KK, false)
   switch (p.k) {
     VTC_CX_FUSED(5);
     VTC_CX_FUSED(8);
     VTC_CX_FUSED(11);
   }
 #undef VTC_CX_FUSED
+#undef VTC_CX_FUSED_T
   set_error("conv bf16x3: kernel size not instantiated");
   return VTC_ERR_UNSUPPORTED;
 }
 
+// dscale != null: f16 operands of sigma_D D (dscale = {sigma_D, 1 / sigma_D},
+// already on the device)
 static int cx_pack(const float* D, const ConvGeo& g, const CxPlan& p,
-                   uint16_t* syn, uint16_t* ana, hipStream_t st) {
-  hipLaunchKernelGGL(conv_x3_pack_kernel, dim3(256), dim3(256), 0, st, D, syn,
-                     ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks);
+                   uint16_t* syn, uint16_t* ana, const float* dscale,
+                   hipStream_t st) {
+  if (dscale)
+    hipLaunchKernelGGL(conv_x3_pack_kernel<true>, dim3(256), dim3(256), 0, st,
+                       D, syn, ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks,
+                       dscale);
+  else
+    hipLaunchKernelGGL(conv_x3_pack_kernel<false>, dim3(256), dim3(256), 0, st,
+                       D, syn, ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks,
+                       dscale);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
 
-template <int K>
+template <int K, bool F16>
 static int cx_launch_synth_k(const float* Y, const uint16_t* syn,
                              const float* X, float* R, const ConvGeo& g,
-                             const CxPlan& p, hipStream_t st) {
+                             const CxPlan& p, const CxScales& sc,
+                             hipStream_t st) {
   using Dm = CxDims<K>;
   const int tiles_x = (int)ceil_div(g.W, Dm::TW);
   const int tiles_y = (int)ceil_div(g.H, p.th);
   static unsigned long long attr_set = 0;
   if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_synth_x3_kernel<K>),
+        reinterpret_cast<const void*>(conv_synth_x3_kernel<K, F16>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const int64_t blocks = ceil_div(g.b * tiles_x, 8) * 8 * tiles_y;
@@ -1627,36 +1852,43 @@ static int cx_launch_synth_k(const float* Y, const uint16_t* syn,
     set_error("conv bf16x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL(conv_synth_x3_kernel<K>, dim3((unsigned)blocks),
+  hipLaunchKernelGGL((conv_synth_x3_kernel<K, F16>), dim3((unsigned)blocks),
                      dim3(512), p.syn_lds, st, Y, syn, X, R, g, p.s16,
-                     tiles_x, tiles_y, p.syn_rows);
+                     tiles_x, tiles_y, p.syn_rows, sc);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
 
 static int cx_launch_synth(const float* Y, const uint16_t* syn, const float* X,
                            float* R, const ConvGeo& g, const CxPlan& p,
-                           hipStream_t st) {
+                           const CxScales& sc, hipStream_t st) {
+  const bool f16 = sc.dscale != nullptr;
+#define VTC_CX_SYNTH(KK)                                                      \
+  case KK:                                                                    \
+    return f16 ? cx_launch_synth_k<KK, true>(Y, syn, X, R, g, p, sc, st)      \
+               : cx_launch_synth_k<KK, false>(Y, syn, X, R, g, p, sc, st)
   switch (p.k) {
-    case 5: return cx_launch_synth_k<5>(Y, syn, X, R, g, p, st);
-    case 8: return cx_launch_synth_k<8>(Y, syn, X, R, g, p, st);
-    case 11: return cx_launch_synth_k<11>(Y, syn, X, R, g, p, st);
-    case 16: return cx_launch_synth_k<16>(Y, syn, X, R, g, p, st);
+    VTC_CX_SYNTH(5);
+    VTC_CX_SYNTH(8);
+    VTC_CX_SYNTH(11);
+    VTC_CX_SYNTH(16);
   }
+#undef VTC_CX_SYNTH
   set_error("conv bf16x3: kernel size not instantiated");
   return VTC_ERR_UNSUPPORTED;
 }
 
-template <int MA, bool FAST>
+template <int MA, bool FAST, bool F16>
 static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 float* C, const ConvGeo& g, const CxPlan& p,
-                                const ProxParams& pp, hipStream_t st) {
+                                const ProxParams& pp, const CxScales& sc,
+                                hipStream_t st) {
   const int tiles_v = (int)ceil_div(g.cw, kCxStrip);
   const int tiles_u = (int)ceil_div(g.ch, p.ana_rows);
   static unsigned long long attr_set = 0;
   if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA, FAST>),
+        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA, FAST, F16>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
@@ -1665,22 +1897,27 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
     set_error("conv bf16x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST>),
+  hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST, F16>),
                      dim3((unsigned)blocks), dim3(256), p.ana_lds, st, R, ana,
-                     Y, C, g, tiles_v, tiles_u, p.chunks, p.ana_rows, pp);
+                     Y, C, g, tiles_v, tiles_u, p.chunks, p.ana_rows, pp, sc);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
 
 static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
                               float* C, const ConvGeo& g, const CxPlan& p,
-                              const ProxParams& pp, hipStream_t st) {
+                              const ProxParams& pp, const CxScales& sc,
+                              hipStream_t st) {
   const bool fast = pp.fista && pp.mode == VTC_SOFT && !pp.delta_sum;
-  if (p.AC == 64)
-    return fast ? cx_launch_analysis_m<2, true>(R, ana, Y, C, g, p, pp, st)
-                : cx_launch_analysis_m<2, false>(R, ana, Y, C, g, p, pp, st);
-  return fast ? cx_launch_analysis_m<1, true>(R, ana, Y, C, g, p, pp, st)
-              : cx_launch_analysis_m<1, false>(R, ana, Y, C, g, p, pp, st);
+  const bool f16 = sc.dscale != nullptr;
+#define VTC_CX_ANA(MA_, FAST_)                                                \
+  (f16 ? cx_launch_analysis_m<MA_, FAST_, true>(R, ana, Y, C, g, p, pp, sc,   \
+                                                st)                           \
+       : cx_launch_analysis_m<MA_, FAST_, false>(R, ana, Y, C, g, p, pp, sc,  \
+                                                 st))
+  if (p.AC == 64) return fast ? VTC_CX_ANA(2, true) : VTC_CX_ANA(2, false);
+  return fast ? VTC_CX_ANA(1, true) : VTC_CX_ANA(1, false);
+#undef VTC_CX_ANA
 }
 
 // blocks of the gradient kernel (and slabs of its output)

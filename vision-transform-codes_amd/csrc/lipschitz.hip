@@ -223,6 +223,12 @@ constexpr int kLzThreads = 512;
 constexpr int kLzMaxSteps = 256;   // upper end of the step count (arrays)
 constexpr int kLzExtend = 16;      // steps added when the test below fails
 constexpr int kLzLookBack = 8;
+// Agreement asked of the two Ritz values.  The Lanczos vectors are f32 (and
+// normalised with an f32 reciprocal), so the tridiagonal entries -- and with
+// them every Ritz value -- carry noise of a few 2^-24 relative (measured
+// against LAPACK: <= 4e-7; a 1e-7 test called converged 8 x 8 runs
+// unconverged).
+constexpr double kLzAgree = 1e-6;
 
 template <bool STAMP>
 __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   // `k` steps -- and after every kLzExtend more -- the top Ritz value of all
   // steps is compared with that of the steps up to kLzLookBack earlier; the
   // recurrence goes on (to at most k_cap steps) while they differ by more
-  // than 1e-7 relative, and the verdict is written next to the eigenvalue.
+  // than kLzAgree relative, and the verdict is written next to the eigenvalue.
   int target = k, j = 0;
   bool exhausted = false, converged = false;
   double lambda = 0.0;
@@ -381,10 +387,11 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   lambda = tridiagonal_lambda_max_block(alpha, beta2, steps, lo, hi, 4, scratch);
   // converged: the Krylov space is exhausted (the tridiagonal matrix holds the
   // whole reachable spectrum), or the steps up to kLzLookBack ago already had
-  // a Ritz value within 1e-7 of this one
-  converged = exhausted || steps <= kLzLookBack ||
-              !tridiagonal_all_below(alpha, beta2, steps - kLzLookBack,
-                                     lambda - 1e-7 * fabs(lambda));
+  // a Ritz value within kLzAgree of this one
+  converged = exhausted ||
+              (steps > kLzLookBack &&
+               !tridiagonal_all_below(alpha, beta2, steps - kLzLookBack,
+                                      lambda - kLzAgree * fabs(lambda)));
   if (converged || !(lambda == lambda) || steps >= k_cap) break;
   __syncthreads();
   if (tid == 0) beta2[steps - 1] = coupling;
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
           stop_flag = (last_ritz > 0.0 &&
                        fabs(ritz - last_ritz) <= 2e-8 * fabs(ritz)) ? 1 : 0;
           loose_flag = (last_ritz > 0.0 &&
-                        fabs(ritz - last_ritz) <= 1e-7 * fabs(ritz)) ? 1 : 0;
+                        fabs(ritz - last_ritz) <= kLzAgree * fabs(ritz)) ? 1 : 0;
           last_ritz = ritz;
         }
       }
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(kLanczosThreads) void lanczos_large_kernel(
     if (t == 0) {
       // converged: stopped by the test above, Krylov space exhausted (the
       // last coupling vanished), or the latest of the 8-step comparisons
-      // within 1e-7
+      // within kLzAgree
       const bool ok = stop_flag || steps_done < k || loose_flag;
       const float flag = ok ? 1.f : 0.f;
       out[0] = lf;
@@ -595,9 +602,14 @@ static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
   // rounding noise from the copies of converged Ritz values
   // (the kernel checks that itself and goes on, kLzExtend steps at a time up
   // to k_cap = min(2n, kLzMaxSteps), while the value still moves)
+  // Small matrices get n + 16 steps (steps past n only breed copies of
+  // converged Ritz values), so that the look-back comparison has a converged
+  // prefix to look at.
   constexpr int kSteps = 96;
-  int k_small = (int)(2 * n < kSteps ? 2 * n : kSteps);
-  int k_cap = (int)(2 * n < kLzMaxSteps ? 2 * n : kLzMaxSteps);
+  const int64_t want = 2 * n > n + 16 ? 2 * n : n + 16;
+  const int64_t most = 2 * n > n + 48 ? 2 * n : n + 48;
+  int k_small = (int)(want < kSteps ? want : kSteps);
+  int k_cap = (int)(most < kLzMaxSteps ? most : kLzMaxSteps);
   // test hook: VTC_LANCZOS_MAX_STEPS caps both (an unconverged solve on demand)
   static const int forced_cap = getenv("VTC_LANCZOS_MAX_STEPS")
                                     ? atoi(getenv("VTC_LANCZOS_MAX_STEPS")) : 0;

@@ -327,7 +327,7 @@ def _report_unconverged(lam):
   1 / L.  Treated like a failed eigen-solve (vtc_lambda_max's third output)."""
   raise RuntimeError(
       'the Lanczos eigen-solve had not converged at its step limit (top Ritz '
-      'value %r still moving by more than 1e-7 per 8 steps)' % lam)
+      'value %r still moving by more than 1e-6 per 8 steps)' % lam)
 
 
 def lambda_max_device(gram_matrix, host_mirror=None):
