@@ -268,3 +268,42 @@ def test_large_patches_use_the_device_eigen_solver(device, plugins):
                        0.02, 30, precision='f32')
   helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(),
                              helpers.REL_TOL_SHORT, 'n = 400')
+
+
+@pytest.mark.parametrize('mode,tol,flip', [
+    ('f16x3', helpers.REL_TOL_F32, helpers.NEAR_THRESHOLD),
+    ('bf16x3', helpers.REL_TOL_BF16X3, 1e-5)])
+def test_tiled_split_contractions(device, plugins, mode, tol, flip):
+  """Shapes outside the fused kernels (20x20 patches, 500 atoms) on the tiled
+  hi/lo split contractions (gemm_x3.h): f16x3 -- operands in power-of-two
+  scaled units, maxima handed from launch to launch on the device -- at
+  north_star's tolerance over 200 FISTA iterations, bf16x3 at its 3e-5; warm
+  start (the first operand's scale comes from the initial codes), ISTA, and
+  data far from unit scale (the scales are exact powers of two)."""
+  ista_fista = plugins[0]
+  Xn = helpers.gaussian_patches(81, 96, 400)
+  Dn = helpers.unit_rows(82, 500, 400)
+  Xc, Dc = torch.from_numpy(Xn), torch.from_numpy(Dn)
+  eta = sc_oracle.fc_stepsize(Dc)
+  X, D = helpers.to_dev(Xn, device), helpers.to_dev(Dn, device)
+  for iters in (30, 200):
+    ref = sc_oracle.fc_ista_fista(Xc, Dc, 0.02, iters, stepsize=eta)
+    out = ista_fista.run(X, D, 0.02, iters, precision=mode,
+                         stepsize=float(eta))
+    helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), tol,
+                               '%s T=%d' % (mode, iters), max_flip_mag=flip)
+  warm = sc_oracle.fc_ista_fista(Xc, Dc, 0.02, 5, stepsize=eta)
+  ref = sc_oracle.fc_ista_fista(Xc, Dc, 0.02, 20, stepsize=eta,
+                                initial_codes=warm, variant='ista')
+  out = ista_fista.run(X, D, 0.02, 20, precision=mode, stepsize=float(eta),
+                       initial_codes=helpers.to_dev(warm.numpy(), device),
+                       variant='ista')
+  helpers.assert_codes_match(out.cpu().numpy(), ref.numpy(), tol,
+                             mode + ' warm ista', max_flip_mag=flip)
+  if mode == 'f16x3':
+    # 2^30 times larger patches and threshold: codes 2^30 times larger,
+    # bit for bit (every scale in the path is a power of two)
+    base = ista_fista.run(X, D, 0.02, 25, precision=mode, stepsize=float(eta))
+    big = ista_fista.run(X * 2.0 ** 30, D, 0.02 * 2.0 ** 30, 25,
+                         precision=mode, stepsize=float(eta))
+    assert torch.equal(big, base * 2.0 ** 30)

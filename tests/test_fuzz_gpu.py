@@ -1,8 +1,9 @@
 """Randomised parity sweep: random small shapes through every inference path
 (fully-connected f32 / tiled bf16x3 / fused, subspace, convolutional: strided
 patch contractions, stride-1 f32 and bf16x3 kernels) and the cheap-quadratic
-update, each case against the CPU oracle.  Tolerance 2e-5 relative on the
-codes, support identical above 1e-5; dictionary 5e-6."""
+update, each case against the CPU oracle.  Tolerance: 1e-5 relative on the
+codes with support flips only within 2e-6 of the threshold for the exact-f32
+and f16x3 paths, 2e-5 / 1e-5 for bf16x3; dictionary 5e-6."""
 import traceback
 
 import numpy as np
@@ -58,12 +59,13 @@ def test_random_shapes_against_the_oracle(device, seed):
         lam = float(rs.choice([0.005, 0.02, 0.05])); T = int(rs.choice([1, 3, 12, 30]))
         kw = {'variant': str(rs.choice(['ista', 'fista'])),
               'nonnegative_only': bool(rs.rand() < 0.3)}
-        prec = str(rs.choice(['f32', 'bf16x3'])) if (n % 4 == 0 and s % 4 == 0) else 'f32'
+        prec = str(rs.choice(['f32', 'bf16x3', 'f16x3'])) if (n % 4 == 0 and s % 4 == 0) else 'f32'
         eta = sc_oracle.fc_stepsize(torch.from_numpy(D))
         ref = sc_oracle.fc_ista_fista(torch.from_numpy(X), torch.from_numpy(D), lam, T, stepsize=eta, **kw)
         out = ista_fista.run(torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev), lam, T,
                              precision=prec, stepsize=float(eta), **kw)
-        ok = check('fc b=%d n=%d s=%d T=%d %s %r' % (b, n, s, T, prec, kw), out, ref, 2e-5)
+        ok = check('fc b=%d n=%d s=%d T=%d %s %r' % (b, n, s, T, prec, kw), out, ref,
+                   *((2e-5, 1e-5) if prec == 'bf16x3' else (1e-5, 2e-6)))
         if kind == 'upd' and ok:
           h = (0.01 + rs.rand(s)).astype(np.float32)
           refD = torch.from_numpy(D.copy())
@@ -79,11 +81,12 @@ def test_random_shapes_against_the_oracle(device, seed):
         X = (0.1 * rs.randn(b, n)).astype(np.float32); D = unit(s, n)
         groups = [list(range(g * m, g * m + m)) for g in range(G)]
         T = int(rs.choice([2, 10, 25]))
-        prec = str(rs.choice(['f32', 'bf16x3'])) if s % 4 == 0 and n % 4 == 0 else 'f32'
+        prec = str(rs.choice(['f32', 'bf16x3', 'f16x3'])) if s % 4 == 0 and n % 4 == 0 else 'f32'
         ref = sc_oracle.subspace_ista_fista(torch.from_numpy(X), torch.from_numpy(D), groups, 0.03, T)
         out = subspace_ista_fista.run(torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev), groups,
                                       0.03, T, precision=prec)
-        ok = check('sub b=%d n=%d G=%d m=%d T=%d %s' % (b, n, G, m, T, prec), out, ref, 2e-5)
+        ok = check('sub b=%d n=%d G=%d m=%d T=%d %s' % (b, n, G, m, T, prec), out, ref,
+                   *((1e-5, 2e-6) if prec == 'f32' or (prec == 'f16x3' and m != 3) else (2e-5, 1e-5)))
       else:
         k = int(rs.choice([4, 5, 8, 11])); st = int(rs.choice([1, 1, 2, 4]))
         if k % st: st = 1
@@ -100,7 +103,7 @@ def test_random_shapes_against_the_oracle(device, seed):
         ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D), (st, st), pad, 0.05, T, stepsize=step)
         out = conv.run(torch.from_numpy(imgs).to(dev), torch.from_numpy(D).to(dev), (st, st), pad, 0.05, T,
                        stepsize=step, precision=prec)
-        ok = check('conv b=%d s=%d k=%d st=%d %dx%d T=%d' % (b, s, k, st, H, W, T), out, ref, 2e-5)
+        ok = check('conv b=%d s=%d k=%d st=%d %dx%d T=%d' % (b, s, k, st, H, W, T), out, ref, 1e-5, 2e-6)
     except Exception:
       report('case %d (%s): %s' % (c, kind, traceback.format_exc()))
   assert not failures, '\n'.join(failures)

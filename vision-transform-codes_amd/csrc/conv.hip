@@ -452,9 +452,11 @@ static size_t conv_x3_image_bytes(const ConvGeo& g) {
   return cx_plan(g, &p) ? cx_image_bytes(p) + cx_fused_bytes(p) : 0;
 }
 
-// f16x3 scale state (conv_x3.h, CxScales): {sigma_D, 1 / sigma_D} and two
-// slots each for max |R| and max |Y|
-constexpr int kCxStateWords = 64 + 4 * kCxMaxSlotWords;
+// f16x3 scale state (x3_scale.h, CxScales): {sigma_D, 1 / sigma_D} and, per
+// image, two words each for max |R| and max |Y|
+static size_t cx_state_words(const ConvGeo& g) {
+  return 64 + 4 * (size_t)g.b;
+}
 
 static size_t conv_inference_ws(const ConvGeo& g) {
   const size_t code_elems = (size_t)g.b * g.s * g.ch * g.cw;
@@ -465,7 +467,7 @@ static size_t conv_inference_ws(const ConvGeo& g) {
          align_up((size_t)g.s * g.c * g.kh * g.kw * 4, 256) + // Kt
          conv_x3_image_bytes(g) +                             // bf16x3 operands
          patch_workspace_bytes(g) +                           // im2col, Q
-         align_up(kCxStateWords * sizeof(unsigned), 256) +    // f16x3 scales
+         align_up(cx_state_words(g) * sizeof(unsigned), 256) + // f16x3 scales
          256;
 }
 
@@ -570,21 +572,21 @@ extern "C" int vtc_conv_ista_fista(
   float* Cfrag1 = nullptr;          // the last two code iterates of that
   float* Cfrag0 = nullptr;          // kernel, fragment order (CxMaps)
   // f16x3: power-of-two scales of the operands (conv_x3.h, CxScales)
-  unsigned* state = ws.take<unsigned>(kCxStateWords);
+  unsigned* state = ws.take<unsigned>(cx_state_words(g));
   float* dscale = f16 ? reinterpret_cast<float*>(state) : nullptr;
-  unsigned* r_slot[2] = {state + 64, state + 64 + kCxMaxSlotWords};
-  unsigned* y_slot[2] = {state + 64 + 2 * kCxMaxSlotWords,
-                         state + 64 + 3 * kCxMaxSlotWords};
+  unsigned* r_slot[2] = {state + 64, state + 64 + g.b};
+  unsigned* y_slot[2] = {state + 64 + 2 * g.b, state + 64 + 3 * g.b};
+  const int images = (int)g.b;
   if (f16) {
-    VTC_HIP_CHECK(hipMemsetAsync(state, 0, kCxStateWords * sizeof(unsigned),
-                                 st));
+    VTC_HIP_CHECK(hipMemsetAsync(state, 0,
+                                 cx_state_words(g) * sizeof(unsigned), st));
     hipLaunchKernelGGL(cx_array_scale_kernel, dim3(1), dim3(1024), 0, st,
                        dictionary, (int64_t)g.s * g.c * g.kh * g.kw, dscale);
     VTC_LAUNCH_CHECK();
     if (initial_codes) {
-      hipLaunchKernelGGL(cx_array_max_kernel, dim3(1024), dim3(256), 0, st,
-                         initial_codes,
-                         (int64_t)g.b * g.s * g.ch * g.cw, y_slot[0]);
+      hipLaunchKernelGGL(cx_image_max_kernel, dim3(64, (unsigned)g.b),
+                         dim3(256), 0, st, initial_codes,
+                         (int64_t)g.s * g.ch * g.cw, y_slot[0]);
       VTC_LAUNCH_CHECK();
     }
   }
@@ -675,7 +677,7 @@ extern "C" int vtc_conv_ista_fista(
       // writes the codes in the caller's layout.
       if (k == 0) {
         CxScales first{dscale, nullptr, r_slot[0], nullptr, y_slot[0], nullptr,
-                       nullptr};
+                       nullptr, images};
         rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,
                              first, st);
         if (rc != VTC_OK) return rc;
@@ -702,7 +704,7 @@ extern "C" int vtc_conv_ista_fista(
       // the launch reads max |R_k| and clears the slot into which the
       // residual kernel behind it leaves max |R_(k+1)|
       CxScales sc{dscale, r_slot[k & 1], r_slot[(k + 1) & 1],
-                  r_slot[(k + 1) & 1], nullptr, nullptr, nullptr};
+                  r_slot[(k + 1) & 1], nullptr, nullptr, nullptr, images};
       rc = cx_launch_fused(residual, ana_image, synp_image, maps, partial,
                            images_padded, residual, g, xp, pp,
                            k + 1 < num_iters, sc, st);
@@ -713,12 +715,12 @@ extern "C" int vtc_conv_ista_fista(
       // max |Y_(k+1)|; analysis: reads max |R_k|, leaves max |Y_(k+1)|, clears
       // the slot of max |R_(k+1)|
       CxScales syn_sc{dscale, nullptr, r_slot[k & 1], nullptr, y_slot[k & 1],
-                      nullptr, y_slot[(k + 1) & 1]};
+                      nullptr, y_slot[(k + 1) & 1], images};
       rc = cx_launch_synth(Y, syn_image, images_padded, residual, g, xp,
                            syn_sc, st);
       if (rc != VTC_OK) return rc;
       CxScales ana_sc{dscale, r_slot[k & 1], nullptr, r_slot[(k + 1) & 1],
-                      nullptr, y_slot[(k + 1) & 1], nullptr};
+                      nullptr, y_slot[(k + 1) & 1], nullptr, images};
       rc = cx_launch_analysis(residual, ana_image, Y, Cin, g, xp, pp, ana_sc,
                               st);
       if (rc != VTC_OK) return rc;
@@ -860,7 +862,7 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
     // (the gradient stays on the bf16 split: a single product, no iteration
     // to amplify its 2^-17, and its tests hold 5e-6 on the updated kernels)
     const CxScales none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr};
+                        nullptr, 0};
     rc = cx_pack(dictionary, g, xp, syn_image, ana_image, nullptr, st);
     if (rc != VTC_OK) return rc;
     rc = cx_launch_synth(codes, syn_image, images_padded, residual, g, xp,

@@ -31,6 +31,8 @@
 // written once per iteration.
 #pragma once
 
+#include "x3_scale.h"
+
 namespace vtc {
 
 typedef __bf16 cx_bf16x8 __attribute__((ext_vector_type(8)));
@@ -121,104 +123,6 @@ __device__ __forceinline__ void cx_split1(float v, uint16_t& hi, uint16_t& lo) {
     hi = cx_bits(h);
     lo = cx_bits((__bf16)(v - (float)h));
   }
-}
-
-// Slots in which a kernel leaves max |x| of what it wrote, for the kernel that
-// reads it next: 32 words 128 bytes apart per quantity (a block adds to word
-// blockIdx % 32, so that a few thousand atomics do not queue on one address),
-// bit patterns of non-negative floats (ordered like the floats, NaN on top).
-constexpr int kCxMaxWords = 32;
-constexpr int kCxMaxStride = 32;                  // words between two slots
-constexpr int kCxMaxSlotWords = kCxMaxWords * kCxMaxStride;
-
-struct CxScales {
-  const float* dscale;      // {sigma_D, 1 / sigma_D}; null: bf16 mode
-  const unsigned* r_in;     // max |R| of the residual this launch reads
-  unsigned* r_out;          // ... of the residual it writes
-  unsigned* r_zero;         // cleared by this launch (the next writer's slot)
-  const unsigned* y_in;     // the same for the momentum iterate Y
-  unsigned* y_out;
-  unsigned* y_zero;
-};
-
-// power of two that brings a maximum with these bits to [16, 32); 1 for zero,
-// subnormal or non-finite maxima
-__device__ __forceinline__ void cx_scale_of_bits(unsigned bits, float* s,
-                                                 float* inv) {
-  const int e = (int)((bits >> 23) & 0xffu);
-  int field = 258 - e;                            // 127 + 4 - (e - 127)
-  field = field < 2 ? 2 : (field > 252 ? 252 : field);
-  const bool usable = e > 0 && e < 255;
-  *s = usable ? __uint_as_float((unsigned)field << 23) : 1.f;
-  *inv = usable ? __uint_as_float((unsigned)(254 - field) << 23) : 1.f;
-}
-
-// every lane of the calling wave gets the maximum over the slot's words
-__device__ __forceinline__ unsigned cx_read_max(const unsigned* slot) {
-  const int lane = threadIdx.x & 63;
-  unsigned v = slot ? slot[(lane & (kCxMaxWords - 1)) * kCxMaxStride] : 0u;
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) {
-    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-
-// block-wide maximum of m (>= 0) added to the slot; `red` = 16 words of LDS
-// nobody else uses around this call (the barriers are inside)
-__device__ __forceinline__ void cx_publish_max(float m, unsigned* slot,
-                                               unsigned* red) {
-  unsigned v = __float_as_uint(m);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
-    v = o > v ? o : v;
-  }
-  const int wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
-  if ((threadIdx.x & 63) == 0) red[wave] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < waves; ++w) v = red[w] > v ? red[w] : v;
-    atomicMax(slot + (blockIdx.x & (kCxMaxWords - 1)) * kCxMaxStride, v);
-  }
-}
-
-__device__ __forceinline__ void cx_clear_slot(unsigned* slot) {
-  if (slot && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kCxMaxWords)
-    slot[threadIdx.x * kCxMaxStride] = 0u;
-}
-
-// {sigma, 1 / sigma} of a small array (the kernels): one block
-__global__ __launch_bounds__(1024) void cx_array_scale_kernel(
-    const float* __restrict__ x, int64_t count, float* __restrict__ scale) {
-  __shared__ unsigned red[16];
-  float m = 0.f;
-  for (int64_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(x[i]));
-  unsigned v = __float_as_uint(m);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned o = (unsigned)__shfl_xor((int)v, off, 64);
-    v = o > v ? o : v;
-  }
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) v = red[w] > v ? red[w] : v;
-    cx_scale_of_bits(v, scale, scale + 1);
-  }
-}
-
-// max |x| of a large array into a CxScales slot (warm start: the initial
-// codes are the first synthesis operand)
-__global__ __launch_bounds__(256) void cx_array_max_kernel(
-    const float* __restrict__ x, int64_t count, unsigned* __restrict__ slot) {
-  __shared__ unsigned red[16];
-  float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count;
-       i += (int64_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(x[i]));
-  cx_publish_max(m, slot, red);
 }
 
 // ------------------------------------------------------------------ pack
@@ -320,13 +224,7 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   // per launch for 290 MB of code maps.)
   // F16: Y enters as sigma_Y Y, the kernels as sigma_D D; the reconstruction
   // comes back by 1 / (sigma_Y sigma_D) before the image is subtracted
-  float y_scale = 1.f, unscale = 1.f;
-  if (F16) {
-    float inv_y;
-    cx_scale_of_bits(cx_read_max(sc.y_in), &y_scale, &inv_y);
-    unscale = inv_y * sc.dscale[1];
-    cx_clear_slot(sc.y_zero);
-  }
+  if (F16) cx_clear_words(sc.y_zero, sc.images);
   const int64_t strips = g.b * tiles_x;
   const int64_t slot = (int64_t)blockIdx.x >> 3;
   const int64_t strip = (slot / tiles_y) * 8 + (blockIdx.x & 7);
@@ -334,6 +232,12 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   const int tile_y = (int)(slot % tiles_y);
   const int tile_x = (int)(strip % tiles_x);
   const int64_t img = strip / tiles_x;
+  float y_scale = 1.f, unscale = 1.f;
+  if (F16) {
+    float inv_y;
+    cx_scale_of_bits(sc.y_in ? sc.y_in[img] : 0u, &y_scale, &inv_y);
+    unscale = inv_y * sc.dscale[1];
+  }
   {
     const int n16 = plane / 4;                     // 2 planes * 2 B / 16 B
     const uint4* src = reinterpret_cast<const uint4*>(syn_image);
@@ -526,7 +430,8 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   }
   if (F16 && sc.r_out) {
     __syncthreads();                               // priv is free now
-    cx_publish_max(r_max, sc.r_out, reinterpret_cast<unsigned*>(priv));
+    cx_publish_max_word(r_max, sc.r_out + img,
+                        reinterpret_cast<unsigned*>(priv));
   }
 }
 
@@ -564,13 +469,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   // F16: the window enters as sigma_R R, the kernels as sigma_D D; the
   // gradient step takes eta / (sigma_R sigma_D) -- a power-of-two factor
   // commutes with the rounding of eta * G
-  float r_scale = 1.f, eta = pp.eta;
-  if (F16) {
-    float inv_r;
-    cx_scale_of_bits(cx_read_max(sc.r_in), &r_scale, &inv_r);
-    eta = pp.eta * (inv_r * sc.dscale[1]);
-    cx_clear_slot(sc.r_zero);
-  }
+  if (F16) cx_clear_words(sc.r_zero, sc.images);
   float y_max = 0.f;                               // of the next iterate
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int tile_v = slot % tiles_v;
@@ -579,6 +478,12 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int chunk = (int)(band % chunks);
   const int tile_u = (int)((band / chunks) % tiles_u);
   const int64_t img = band / ((int64_t)chunks * tiles_u);
+  float r_scale = 1.f, eta = pp.eta;
+  if (F16) {
+    float inv_r;
+    cx_scale_of_bits(sc.r_in[img], &r_scale, &inv_r);
+    eta = pp.eta * (inv_r * sc.dscale[1]);
+  }
   const int u0 = tile_u * ana_rows, v0 = tile_v * kCxStrip;
   {
     const uint4* src = reinterpret_cast<const uint4*>(
@@ -735,7 +640,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   }
   if (F16 && sc.y_out) {
     __syncthreads();                               // the window is free now
-    cx_publish_max(y_max, sc.y_out, reinterpret_cast<unsigned*>(Rh));
+    cx_publish_max_word(y_max, sc.y_out + img, reinterpret_cast<unsigned*>(Rh));
   }
 }
 
@@ -939,16 +844,25 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   // the kernels as sigma_D D, and the gradient step takes
   // eta / (sigma_R sigma_D); the new iterate enters the synthesis product
   // scaled per code column and the tap sums are scaled back before the fold
-  float r_scale = 1.f, eta = pp.eta, inv_d = 1.f;
+  float eta = pp.eta, inv_d = 1.f;                  // eta: of the current item
   if (F16) {
-    float inv_r;
-    cx_scale_of_bits(cx_read_max(sc.r_in), &r_scale, &inv_r);
     inv_d = sc.dscale[1];
-    eta = pp.eta * (inv_r * inv_d);
-    cx_clear_slot(sc.r_zero);
+    cx_clear_words(sc.r_zero, sc.images);
   }
+  // residual scale of an item's image and the step that undoes it
+  auto item_scale = [&](const CxItem& it, float* rs, float* eta_eff) {
+    *rs = 1.f;
+    *eta_eff = pp.eta;
+    if (F16 && it.valid) {
+      float inv_r;
+      cx_scale_of_bits(sc.r_in[it.img], rs, &inv_r);
+      *eta_eff = pp.eta * (inv_r * inv_d);
+    }
+  };
   CxItem cur = decode(rank);
   if (!cur.valid) return;                           // whole block
+  float rs_cur, eta_cur, rs_nxt, eta_nxt;
+  item_scale(cur, &rs_cur, &eta_cur);
 
   // residual window of an item: global -> registers -> bf16 hi / lo planes
   float wreg[F::WIN_REGS];
@@ -964,7 +878,7 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
                     ? Rimg[y * (int)g.W + x] : 0.f;
     }
   };
-  auto window_store = [&](int buf) {
+  auto window_store = [&](int buf, float r_scale) {
     uint16_t* Wb = Win + buf * F::WIN_BUF;
 #pragma unroll
     for (int q = 0; q < F::WIN_REGS; ++q) {
@@ -996,7 +910,7 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       for (int i = tid; i < splane / 4; i += 512) sdst[i] = ssrc[i];
     }
     window_fetch(cur);
-    window_store(0);
+    window_store(0, rs_cur);
   }
   __syncthreads();
   stamp(0);
@@ -1220,16 +1134,18 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
   load_tile(cur, 0, yA, cA);
   load_tile(cur, 1, yB, cB);
   CxItem nxt = decode(rank + nper);
+  item_scale(nxt, &rs_nxt, &eta_nxt);
   window_fetch(nxt);
   for (int i = 0; cur.valid; ++i) {
     const int buf = i & 1;
     const bool row_ok = cur.u0 + wave < g.ch;        // wave-uniform
     const uint16_t* Wb = Win + buf * F::WIN_BUF;
+    eta = eta_cur;
     // The window of the NEXT item goes to the other buffer now: it was last
     // read before the previous barrier, and everything this wave has in
     // flight (the next window, this item's code maps) was issued most of an
     // item ago -- the one full wait on memory per item costs nothing here.
-    window_store(buf ^ 1);
+    window_store(buf ^ 1, rs_nxt);
     const CxItem nn = decode(rank + (i + 2) * nper);
     if (row_ok) {
       f32x16 acc[2];
@@ -1333,6 +1249,9 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     stamp(6);
     cur = nxt;
     nxt = nn;
+    rs_cur = rs_nxt;
+    eta_cur = eta_nxt;
+    item_scale(nxt, &rs_nxt, &eta_nxt);
   }
   if (STAMP && lane == 0) {
     for (int q = 0; q < 9; ++q) atomicAdd(stamps + q, st_acc[q]);
@@ -1402,7 +1321,8 @@ __global__ void conv_from_fragments_kernel(const float* __restrict__ src,
 }
 
 // residual = mask * (sum of the partial tiles covering the pixel - image)
-// r_max_out (may be null): the slot that receives max |R| (CxScales)
+// grid = (blocks per image, images); r_max_out (may be null): the per-image
+// words that receive max |R| (CxScales)
 template <int K>
 __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
                                            const float* __restrict__ X,
@@ -1412,22 +1332,12 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
   using F = CxFused<K>;
   __shared__ unsigned red[16];
   float r_max = 0.f;
-  const int64_t total = g.b * (int64_t)g.H * g.W;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    int x, y;
-    int64_t img;
-    if (total < ((int64_t)1 << 31)) {               // 32-bit index arithmetic
-      const unsigned i32 = (unsigned)i, W = (unsigned)g.W;
-      const unsigned row = i32 / W, im = row / (unsigned)g.H;
-      x = (int)(i32 - row * W);
-      y = (int)(row - im * (unsigned)g.H);
-      img = im;
-    } else {
-      x = (int)(i % g.W);
-      y = (int)((i / g.W) % g.H);
-      img = i / ((int64_t)g.W * g.H);
-    }
+  const int64_t img = blockIdx.y;
+  const unsigned per_image = (unsigned)g.H * (unsigned)g.W;
+  for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < per_image;
+       p += gridDim.x * blockDim.x) {
+    const unsigned W = (unsigned)g.W;
+    const int y = (int)(p / W), x = (int)(p - (unsigned)y * W);
     int tu_lo = (y - F::TH + F::ROWS) / F::ROWS;    // ceil((y - TH + 1) / ROWS)
     if (y - F::TH + 1 <= 0) tu_lo = 0;
     int tu_hi = y / F::ROWS;
@@ -1446,11 +1356,12 @@ __global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
           sum = add_rn(sum, tile[(y - tu * F::ROWS) * F::TW +
                                  (x - tv * F::COLS)]);
         }
+    const int64_t i = img * (int64_t)per_image + p;
     const float rv = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
     R[i] = rv;
     r_max = fmaxf(r_max, fabsf(rv));
   }
-  if (r_max_out) cx_publish_max(r_max, r_max_out, red);
+  if (r_max_out) cx_publish_max_word(r_max, r_max_out + img, red);
 }
 
 // ---------------------------------------------- dictionary gradient (a8/a9)
@@ -1777,12 +1688,12 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
               (double)host[q] / (double)host[9]);
   }
   if (do_synth) {
-    const int64_t pixels = g.b * (int64_t)g.H * g.W;
-    int64_t rblocks = ceil_div(pixels, 256);
-    if (rblocks > 65535) rblocks = 65535;
-    hipLaunchKernelGGL(conv_partial_reduce_kernel<K>, dim3((unsigned)rblocks),
-                       dim3(256), 0, st, partial, X, R_next, g, tiles_v,
-                       tiles_u, p.chunks, F16 ? sc.r_out : nullptr);
+    int64_t rblocks = ceil_div((int64_t)g.H * g.W, 256);
+    if (rblocks > 4096) rblocks = 4096;
+    hipLaunchKernelGGL(conv_partial_reduce_kernel<K>,
+                       dim3((unsigned)rblocks, (unsigned)g.b), dim3(256), 0,
+                       st, partial, X, R_next, g, tiles_v, tiles_u, p.chunks,
+                       F16 ? sc.r_out : nullptr);
     VTC_LAUNCH_CHECK();
   }
   return VTC_OK;

@@ -47,23 +47,29 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int slices,
 __global__ void slab_reduce_minus_kernel(const float* __restrict__ slabs,
                                          int slices, int64_t count,
                                          const float* __restrict__ X,
-                                         float* __restrict__ out) {
+                                         float* __restrict__ out,
+                                         unsigned* max_out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float mx = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
        i += stride) {
     float acc = slabs[i];
     for (int z = 1; z < slices; ++z) acc += slabs[(int64_t)z * count + i];
-    out[i] = sub_rn(acc, X[i]);
+    const float r = sub_rn(acc, X[i]);
+    out[i] = r;
+    mx = fmaxf(mx, fabsf(r));
   }
+  if (max_out) cx_publish_max_wave(mx, max_out);   // f16 split: x3_scale.h
 }
 
 int launch_slab_reduce_minus(const float* slabs, int slices, int64_t count,
-                             const float* X, float* out, hipStream_t st) {
+                             const float* X, float* out, hipStream_t st,
+                             unsigned* max_out) {
   if (count <= 0) return VTC_OK;
   int64_t blocks = ceil_div(count, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(slab_reduce_minus_kernel, dim3((unsigned)blocks),
-                     dim3(256), 0, st, slabs, slices, count, X, out);
+                     dim3(256), 0, st, slabs, slices, count, X, out, max_out);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }

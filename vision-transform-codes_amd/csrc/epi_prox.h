@@ -36,6 +36,10 @@ struct EpiGroupProx {
   // (their L2s are not coherent within a launch).
   float* Yo = nullptr;
   float* Co = nullptr;
+  // f16 split of the next product (x3_scale.h): the slot that receives the
+  // maximum of the new iterate |Y'|
+  unsigned* max_out = nullptr;
+  float mx = 0.f;
   __device__ __forceinline__ void resolve() {
     if (eta_dev) {
       eta = *eta_dev;
@@ -156,8 +160,10 @@ struct EpiGroupProx {
           cn = mul_rn(p[i], scale);
         }
         const float d = sub_rn(cn, buf[16 + 4 * q + i]);
-        y4[i] = __float_as_uint(fista ? add_rn(cn, mul_rn(beta, d)) : cn);
+        const float yn = fista ? add_rn(cn, mul_rn(beta, d)) : cn;
+        y4[i] = __float_as_uint(yn);
         c4[i] = __float_as_uint(cn);
+        mx = fmaxf(mx, fabsf(yn));
         if (delta_sum) local += (double)(fabsf(d) / eta);
       }
       __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yws, off,
@@ -173,6 +179,7 @@ struct EpiGroupProx {
       const double w = wave_sum(local);
       if ((threadIdx.x & 63) == 0) atomicAdd(delta_sum, w);
     }
+    if (max_out) cx_publish_max_wave(mx, max_out);
   }
 };
 

@@ -80,6 +80,10 @@ void fista_betas(int num_iters, std::vector<float>* out) {
 int launch_transpose(const float* in, float* out, int64_t rows, int64_t cols,
                      hipStream_t st);  // subspace.hip
 
+// f16x3 scale state of the tiled path (x3_scale.h): {sigma_D, 1 / sigma_D} and
+// two slots each for max |Y| and max |R|
+constexpr int kX3StateWords = 64 + 4 * kCxMaxSlotWords;
+
 static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
   size_t bytes = 0;
   bytes += 3 * align_up((size_t)b * s * sizeof(float), 256);  // Y, Y', C'
@@ -88,15 +92,17 @@ static size_t generic_workspace_bytes(int64_t b, int64_t n, int64_t s) {
   bytes += align_up((size_t)gemm_x3_want_slices(b, n, s) * b * n *
                         sizeof(float), 256);  // split-K slabs
   bytes += 256;                                           // stop accumulator
+  bytes += align_up(kX3StateWords * sizeof(unsigned), 256);  // f16x3 scales
   return bytes;
 }
 
-// x3 = false: exact-f32 MFMA; x3 = true: bf16 hi/lo split tiles (gemm_x3.h)
+// x3 = false: exact-f32 MFMA; x3 = true: hi/lo split tiles (gemm_x3.h), the
+// f16 split in power-of-two scaled units when f16 is set, else bf16
 static int run_generic(const float* images, const float* dictionary,
                        const float* initial_codes, float* codes, int64_t b,
                        int64_t n, int64_t s, float eta, const float* eta_dev,
                        float lam, int num_iters, int variant, int threshold,
-                       float eps, bool x3, void* workspace,
+                       float eps, bool x3, bool f16, void* workspace,
                        size_t workspace_bytes, int* iters_run, hipStream_t st) {
   // lambda * eta: the Python float rounded to f32, then one f32 multiply (the
   // epilogues redo it on the device when eta lives there)
@@ -115,6 +121,24 @@ static int run_generic(const float* images, const float* dictionary,
   const int k1_slices = x3 ? gemm_x3_want_slices(b, n, s) : 1;
   float* slabs = ws.take<float>((size_t)gemm_x3_want_slices(b, n, s) * b * n);
   double* delta_sum = ws.take<double>(1);
+  unsigned* state = ws.take<unsigned>(kX3StateWords);
+  f16 = f16 && x3;
+  float* dscale = f16 ? reinterpret_cast<float*>(state) : nullptr;
+  unsigned* y_slot[2] = {state + 64, state + 64 + kCxMaxSlotWords};
+  unsigned* r_slot[2] = {state + 64 + 2 * kCxMaxSlotWords,
+                         state + 64 + 3 * kCxMaxSlotWords};
+  if (f16) {
+    VTC_HIP_CHECK(hipMemsetAsync(state, 0, kX3StateWords * sizeof(unsigned),
+                                 st));
+    hipLaunchKernelGGL(cx_array_scale_kernel, dim3(1), dim3(1024), 0, st,
+                       dictionary, s * n, dscale);
+    VTC_LAUNCH_CHECK();
+    if (initial_codes) {
+      hipLaunchKernelGGL(cx_array_max_kernel, dim3(1024), dim3(256), 0, st,
+                         initial_codes, b * s, y_slot[0]);
+      VTC_LAUNCH_CHECK();
+    }
+  }
 
   const bool fista = (variant == VTC_FISTA);
   float* Y = fista ? Ybuf : codes;  // ISTA evaluates the gradient at the codes
@@ -149,14 +173,27 @@ static int run_generic(const float* images, const float* dictionary,
     if (!fista) Y = Cin;   // ISTA evaluates the gradient at the codes
     // R = Y D - X : A = Y (b,s) k-contiguous, B = D (s,n) = [K][N]
     EpiMinus e1{R, images, n, n};
+    // f16 split: the residual product reads max |Y_k|, leaves max |R_k| and
+    // clears the slot of max |Y_(k+1)|; the gradient product reads max |R_k|,
+    // leaves max |Y_(k+1)| and clears the slot of max |R_(k+1)|
+    X3Scale sc1, sc2;
+    if (f16) {
+      sc1.b_scale = sc2.b_scale = dscale;
+      sc1.a_max = y_slot[k & 1];
+      sc1.clear = y_slot[(k + 1) & 1];
+      sc2.a_max = r_slot[k & 1];
+      sc2.clear = r_slot[(k + 1) & 1];
+      e1.max_out = r_slot[k & 1];
+    }
     int rc;
     if (x3 && k1_slices > 1) {
       EpiSlab es{slabs, b * n, n};
-      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, es, st, k1_slices);
+      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, es, st, k1_slices, sc1);
       if (rc == VTC_OK)
-        rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st);
+        rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st,
+                                      f16 ? r_slot[k & 1] : nullptr);
     } else if (x3) {
-      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st);
+      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st, 1, sc1);
     } else {
       rc = launch_gemm_f32<true, false>(Y, s, dictionary, n, b, n, s, 1, e1,
                                         st);
@@ -177,7 +214,8 @@ static int run_generic(const float* images, const float* dictionary,
                                threshold, eta_dev, lam};
       e2.Yo = fista ? Yout : Cout;
       e2.Co = Cout;
-      rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st)
+      if (f16) e2.max_out = y_slot[(k + 1) & 1];
+      rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st, 1, sc2)
               : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
                                             e2, st);
     } else {
@@ -300,13 +338,13 @@ static int fc_ista_fista_impl(const float* images, const float* dictionary,
                       stepsize, stepsize_dev, sparsity_weight, num_iters,
                       variant, threshold, precision, workspace,
                       workspace_bytes, iters_run, st);
-  // elsewhere the split-operand modes both run on the tiled bf16 hi/lo
-  // contraction
+  // elsewhere the split-operand modes run on the tiled hi/lo contraction
+  // (gemm_x3.h): f16x3 in scaled units, bf16x3 as is
   return run_generic(images, dictionary, initial_codes, codes, b, n, s,
                      stepsize, stepsize_dev, sparsity_weight, num_iters,
                      variant, threshold, early_stopping_epsilon,
-                     precision != VTC_F32, workspace, workspace_bytes,
-                     iters_run, st);
+                     precision != VTC_F32, precision == VTC_F16X3, workspace,
+                     workspace_bytes, iters_run, st);
 }
 
 extern "C" int vtc_fc_ista_fista(const float* images, const float* dictionary,

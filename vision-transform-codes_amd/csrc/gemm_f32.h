@@ -14,6 +14,7 @@
 #pragma once
 
 #include "common.h"
+#include "x3_scale.h"
 
 #include <type_traits>
 
@@ -394,11 +395,18 @@ struct EpiMinus {  // C = acc - X   (the reconstruction residual)
   float* C;
   const float* X;
   int64_t ldc, ldx;
+  // f16 split of the NEXT product (x3_scale.h): the slot that receives max |C|
+  unsigned* max_out = nullptr;
+  float mx = 0.f;
   __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
-                                             int) const {
-    C[row * ldc + col] = sub_rn(v, X[row * ldx + col]);
+                                             int) {
+    const float r = sub_rn(v, X[row * ldx + col]);
+    C[row * ldc + col] = r;
+    mx = fmaxf(mx, fabsf(r));
   }
-  __device__ __forceinline__ void block_end() const {}
+  __device__ __forceinline__ void block_end() const {
+    if (max_out) cx_publish_max_wave(mx, max_out);
+  }
 };
 
 // out[i] = sum_z slabs[z][i], z ascending: a fixed order, so the result does

@@ -19,6 +19,7 @@
 
 #include "common.h"
 #include "gemm_f32.h"
+#include "x3_scale.h"
 
 namespace vtc {
 
@@ -28,7 +29,73 @@ struct GemmX3Args {
   int64_t M, N, K;
   int64_t lda, ldb;
   int64_t k_chunk;   // K range per blockIdx.y slice (split-K), multiple of 32
+  // f16 split (kernels instantiated with F16 = true; x3_scale.h): the B
+  // operand enters as b_scale[0] * B (a per-call constant, b_scale[1] its
+  // inverse), the A operand times the power of two that brings max |A| --
+  // left in `a_max` by the kernel that wrote A -- to [16, 32); the
+  // accumulators are scaled back before the epilogue sees them.  `clear`: a
+  // slot this launch zeroes for a later writer (may be null).
+  const float* b_scale = nullptr;
+  const unsigned* a_max = nullptr;
+  unsigned* clear = nullptr;
 };
+
+typedef _Float16 x3_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 x3_mfma(const uint4& a, const uint4& b,
+                                          const f32x16& c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(
+        __builtin_bit_cast(x3_f16x8, a), __builtin_bit_cast(x3_f16x8, b), c, 0,
+        0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+      __builtin_bit_cast(x3_bf16x8, a), __builtin_bit_cast(x3_bf16x8, b), c, 0,
+      0, 0);
+}
+
+// four values (times a power-of-two scale) -> packed hi and lo parts
+template <bool F16>
+__device__ __forceinline__ void x3_split4(const float (&v)[4], float scale,
+                                          uint2* hi_out, uint2* lo_out) {
+  if (F16) {
+    x3_f16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float x = v[k] * scale;
+      hi[k] = (_Float16)x;
+      lo[k] = (_Float16)(x - (float)hi[k]);
+    }
+    *hi_out = __builtin_bit_cast(uint2, hi);
+    *lo_out = __builtin_bit_cast(uint2, lo);
+  } else {
+    x3_bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)v[k];
+      lo[k] = (__bf16)(v[k] - (float)hi[k]);
+    }
+    *hi_out = __builtin_bit_cast(uint2, hi);
+    *lo_out = __builtin_bit_cast(uint2, lo);
+  }
+}
+
+// operand scales of a launch: A, B, and the factor that undoes both
+template <bool F16>
+__device__ __forceinline__ void x3_launch_scales(const GemmX3Args& g,
+                                                 float* a_scale,
+                                                 float* b_scale,
+                                                 float* unscale) {
+  *a_scale = *b_scale = *unscale = 1.f;
+  if (F16) {
+    float inv_a;
+    cx_scale_of_bits(cx_read_max(g.a_max), a_scale, &inv_a);
+    *b_scale = g.b_scale[0];
+    *unscale = inv_a * g.b_scale[1];
+    cx_clear_slot(g.clear);
+  }
+}
 
 __device__ __forceinline__ int x3_lds_off(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
@@ -59,28 +126,26 @@ __device__ __forceinline__ void x3_stage_load(const float* P, int64_t ld,
   }
 }
 
-// registers -> LDS as bf16 hi / lo parts
+// registers -> LDS as 16-bit hi / lo parts
+template <bool F16>
 __device__ __forceinline__ void x3_stage_store(char* hi_base, char* lo_base,
                                                int tid,
-                                               const float4 (&regs)[4]) {
+                                               const float4 (&regs)[4],
+                                               float scale) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int f = tid + i * 256;
     const int line = f >> 3, kq = f & 7;
     const float v[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
-    x3_bf16x4 hi, lo;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      hi[k] = (__bf16)v[k];
-      lo[k] = (__bf16)(v[k] - (float)hi[k]);
-    }
+    uint2 hi, lo;
+    x3_split4<F16>(v, scale, &hi, &lo);
     const int off = x3_lds_off(line, kq >> 1) + 8 * (kq & 1);
-    *reinterpret_cast<uint2*>(hi_base + off) = __builtin_bit_cast(uint2, hi);
-    *reinterpret_cast<uint2*>(lo_base + off) = __builtin_bit_cast(uint2, lo);
+    *reinterpret_cast<uint2*>(hi_base + off) = hi;
+    *reinterpret_cast<uint2*>(lo_base + off) = lo;
   }
 }
 
-template <class Epi>
+template <class Epi, bool F16>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   // [buf][A_hi, A_lo, B_hi, B_lo][128 rows][64 B]
   __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
@@ -110,6 +175,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
     tile_m = (int64_t)blockIdx.x / tiles_n;
     tile_n = (int64_t)blockIdx.x % tiles_n;
   }
+  float a_scale, b_scale, unscale;
+  x3_launch_scales<F16>(g, &a_scale, &b_scale, &unscale);
   if (tile_m >= tiles_m) return;                   // whole block (grid padding)
   const int64_t m0 = tile_m * kX3BM;
   const int64_t n0 = tile_n * kX3BN;
@@ -137,8 +204,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
   float4 ra[4], rb[4];
   x3_stage_load(g.A, g.lda, m0, g.M, k_begin, k_end, tid, ra);
   x3_stage_load(g.B, g.ldb, n0, g.N, k_begin, k_end, tid, rb);
-  x3_stage_store(lds[0][0], lds[0][1], tid, ra);
-  x3_stage_store(lds[0][2], lds[0][3], tid, rb);
+  x3_stage_store<F16>(lds[0][0], lds[0][1], tid, ra, a_scale);
+  x3_stage_store<F16>(lds[0][2], lds[0][3], tid, rb, b_scale);
   __syncthreads();
 
   int cur = 0;
@@ -170,24 +237,26 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(x3_bf16x8, ah[mi]),
-              __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(x3_bf16x8, ah[mi]),
-              __builtin_bit_cast(x3_bf16x8, bl[ni]), acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(x3_bf16x8, al[mi]),
-              __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = x3_mfma<F16>(ah[mi], bh[ni], acc[mi][ni]);
+          acc[mi][ni] = x3_mfma<F16>(ah[mi], bl[ni], acc[mi][ni]);
+          acc[mi][ni] = x3_mfma<F16>(al[mi], bh[ni], acc[mi][ni]);
         }
       }
     }
     if (more) {
-      x3_stage_store(lds[cur ^ 1][0], lds[cur ^ 1][1], tid, ra);
-      x3_stage_store(lds[cur ^ 1][2], lds[cur ^ 1][3], tid, rb);
+      x3_stage_store<F16>(lds[cur ^ 1][0], lds[cur ^ 1][1], tid, ra, a_scale);
+      x3_stage_store<F16>(lds[cur ^ 1][2], lds[cur ^ 1][3], tid, rb, b_scale);
     }
     __syncthreads();
     cur ^= 1;
+  }
+  if (F16) {                                       // back to the caller's units
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= unscale;
   }
 
   if constexpr (kPipe) {
@@ -233,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3Args g, Epi epi) {
 // accumulator and staging registers per wave let four waves share a SIMD (16
 // per CU instead of 8): the residual product of the subspace / tiled FC paths
 // runs latency bound on the operand loads with 8.
-template <class Epi>
+template <class Epi, bool F16>
 __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
   __shared__ __attribute__((aligned(16))) char lds[2][4][kX3TileBytes];
   resolve_epilogue(epi, 0);
@@ -253,6 +322,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
     tile_m = (int64_t)blockIdx.x / tiles_n;
     tile_n = (int64_t)blockIdx.x % tiles_n;
   }
+  float a_scale, b_scale, unscale;
+  x3_launch_scales<F16>(g, &a_scale, &b_scale, &unscale);
   if (tile_m >= tiles_m) return;
   const int64_t m0 = tile_m * kX3BM;
   const int64_t n0 = tile_n * kX3BN;
@@ -296,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
     }
   };
   auto stage_store = [&](char* hi_base, char* lo_base,
-                         const x3_u32x4 (&regs)[2]) {
+                         const x3_u32x4 (&regs)[2], float scale) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + i * 512;
@@ -305,15 +376,11 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
                           __uint_as_float(regs[i][1]),
                           __uint_as_float(regs[i][2]),
                           __uint_as_float(regs[i][3])};
-      x3_bf16x4 hi, lo;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        hi[k] = (__bf16)v[k];
-        lo[k] = (__bf16)(v[k] - (float)hi[k]);
-      }
+      uint2 hi, lo;
+      x3_split4<F16>(v, scale, &hi, &lo);
       const int off = x3_lds_off(line, kq >> 1) + 8 * (kq & 1);
-      *reinterpret_cast<uint2*>(hi_base + off) = __builtin_bit_cast(uint2, hi);
-      *reinterpret_cast<uint2*>(lo_base + off) = __builtin_bit_cast(uint2, lo);
+      *reinterpret_cast<uint2*>(hi_base + off) = hi;
+      *reinterpret_cast<uint2*>(lo_base + off) = lo;
     }
   };
   auto compute = [&](int cur) {
@@ -336,15 +403,9 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(x3_bf16x8, ah),
-            __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(x3_bf16x8, ah),
-            __builtin_bit_cast(x3_bf16x8, bl[ni]), acc[ni], 0, 0, 0);
-        acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(x3_bf16x8, al),
-            __builtin_bit_cast(x3_bf16x8, bh[ni]), acc[ni], 0, 0, 0);
+        acc[ni] = x3_mfma<F16>(ah, bh[ni], acc[ni]);
+        acc[ni] = x3_mfma<F16>(ah, bl[ni], acc[ni]);
+        acc[ni] = x3_mfma<F16>(al, bh[ni], acc[ni]);
       }
     }
   };
@@ -354,24 +415,24 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
   x3_u32x4 a0[2], b0[2], a1[2], b1[2];
   stage_load(ars, g.lda, k_of(0), a0);
   stage_load(brs, g.ldb, k_of(0), b0);
-  stage_store(lds[0][0], lds[0][1], a0);
-  stage_store(lds[0][2], lds[0][3], b0);
+  stage_store(lds[0][0], lds[0][1], a0, a_scale);
+  stage_store(lds[0][2], lds[0][3], b0, b_scale);
   __syncthreads();
   if (nk > 1) { stage_load(ars, g.lda, k_of(1), a0); stage_load(brs, g.ldb, k_of(1), b0); }
   if (nk > 2) { stage_load(ars, g.lda, k_of(2), a1); stage_load(brs, g.ldb, k_of(2), b1); }
   for (int kt = 0; kt < nk; kt += 2) {
     compute(0);                                          // step kt
     if (kt + 1 < nk) {
-      stage_store(lds[1][0], lds[1][1], a0);             // operands of kt+1
-      stage_store(lds[1][2], lds[1][3], b0);
+      stage_store(lds[1][0], lds[1][1], a0, a_scale);    // operands of kt+1
+      stage_store(lds[1][2], lds[1][3], b0, b_scale);
     }
     __syncthreads();
     if (kt + 3 < nk) { stage_load(ars, g.lda, k_of(kt + 3), a0); stage_load(brs, g.ldb, k_of(kt + 3), b0); }
     if (kt + 1 < nk) {
       compute(1);                                        // step kt+1
       if (kt + 2 < nk) {
-        stage_store(lds[0][0], lds[0][1], a1);           // operands of kt+2
-        stage_store(lds[0][2], lds[0][3], b1);
+        stage_store(lds[0][0], lds[0][1], a1, a_scale);  // operands of kt+2
+        stage_store(lds[0][2], lds[0][3], b1, b_scale);
       }
       __syncthreads();
       if (kt + 4 < nk) { stage_load(ars, g.lda, k_of(kt + 4), a1); stage_load(brs, g.ldb, k_of(kt + 4), b1); }
@@ -384,7 +445,8 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel8(GemmX3Args g, Epi epi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row < g.M && col < g.N) epi(row, col, acc[ni][r], z);
+      if (row < g.M && col < g.N)
+        epi(row, col, F16 ? acc[ni][r] * unscale : acc[ni][r], z);
     }
   }
   epi.block_end();
@@ -396,16 +458,28 @@ static inline bool gemm_x3_usable(const float* A, int64_t lda, const float* B,
   return gemm_vec_ok(A, lda) && gemm_vec_ok(B, ldb);
 }
 
+// The f16 split of a launch (GemmX3Args): all null = bf16 split.
+struct X3Scale {
+  const float* b_scale = nullptr;
+  const unsigned* a_max = nullptr;
+  unsigned* clear = nullptr;
+};
+
 // k_slices > 1 => split-K: the epilogue receives the slice index (EpiSlab).
 template <class Epi>
 static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
                           int64_t ldb, int64_t M, int64_t N, int64_t K,
-                          Epi epi, hipStream_t st, int k_slices = 1) {
+                          Epi epi, hipStream_t st, int k_slices = 1,
+                          X3Scale sc = X3Scale()) {
   if (M <= 0 || N <= 0) return VTC_OK;
   if (k_slices < 1) k_slices = 1;
   int64_t chunk = ceil_div(ceil_div(K, k_slices), kX3BK) * kX3BK;
   if (chunk < kX3BK) chunk = kX3BK;
   GemmX3Args g{A, B, M, N, K, lda, ldb, chunk};
+  g.b_scale = sc.b_scale;
+  g.a_max = sc.a_max;
+  g.clear = sc.clear;
+  const bool f16 = sc.b_scale != nullptr;
   // row blocks padded to a multiple of 8 (see the block -> tile map)
   const int64_t tiles = ceil_div(ceil_div(M, kX3BM), 8) * 8 *
                         ceil_div(N, kX3BN);
@@ -417,11 +491,21 @@ static int launch_gemm_x3(const float* A, int64_t lda, const float* B,
   if constexpr (!epi_whole_tile<Epi>::value) {
     // plain epilogues: the eight-wave kernel (same-box A/B: tiled FC path
     // 6.02 -> 5.65 ms, configs[3] 41.5 -> 41.2 ms)
-    hipLaunchKernelGGL((gemm_x3_kernel8<Epi>), grid, dim3(512), 0, st, g, epi);
+    if (f16)
+      hipLaunchKernelGGL((gemm_x3_kernel8<Epi, true>), grid, dim3(512), 0, st,
+                         g, epi);
+    else
+      hipLaunchKernelGGL((gemm_x3_kernel8<Epi, false>), grid, dim3(512), 0, st,
+                         g, epi);
     VTC_LAUNCH_CHECK();
     return VTC_OK;
   }
-  hipLaunchKernelGGL((gemm_x3_kernel<Epi>), grid, dim3(256), 0, st, g, epi);
+  if (f16)
+    hipLaunchKernelGGL((gemm_x3_kernel<Epi, true>), grid, dim3(256), 0, st, g,
+                       epi);
+  else
+    hipLaunchKernelGGL((gemm_x3_kernel<Epi, false>), grid, dim3(256), 0, st, g,
+                       epi);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
@@ -448,7 +532,9 @@ static inline int gemm_x3_want_slices(int64_t M, int64_t N, int64_t K) {
 }
 
 // out = sum_z slabs[z] - X   (fixed order; the residual of a split-K product)
+// max_out (may be null): x3_scale.h slot that receives max |out|
 int launch_slab_reduce_minus(const float* slabs, int slices, int64_t count,
-                             const float* X, float* out, hipStream_t st);
+                             const float* X, float* out, hipStream_t st,
+                             unsigned* max_out = nullptr);
 
 }  // namespace vtc

@@ -44,11 +44,13 @@ static int launch_grad_prox(bool x3, const float* R, const float* Dg, float* Y,
                             float* C, float* Yo, float* Co, int64_t b,
                             int64_t slots, int64_t n, float eta, float cutoff,
                             float beta, int fista, double* delta_sum,
-                            hipStream_t st) {
+                            hipStream_t st, X3Scale sc = X3Scale(),
+                            unsigned* y_max_out = nullptr) {
   EpiGroupProx<M> e{Y, C, slots, eta, cutoff, beta, fista, delta_sum, 0.0, 0};
   e.Yo = Yo;
   e.Co = Co;
-  return x3 ? launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st)
+  e.max_out = y_max_out;
+  return x3 ? launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st, 1, sc)
             : launch_gemm_f32<true, true>(R, n, Dg, n, b, slots, n, 1, e, st);
 }
 
@@ -228,12 +230,16 @@ static bool launch_group_prox_pow2(float* Y, float* C, int64_t b,
   return false;
 }
 
+// f16x3 scale state of the tiled path (x3_scale.h)
+constexpr int kSubStateWords = 64 + 4 * kCxMaxSlotWords;
+
 static size_t subspace_ws_bytes(int64_t b, int64_t n, int64_t slots) {
   return 3 * align_up((size_t)b * slots * sizeof(float), 256) +  // Y, Y', C'
          align_up((size_t)b * n * sizeof(float), 256) +       // R
          align_up((size_t)slots * n * sizeof(float), 256) +   // Dg^T (bf16x3)
          align_up((size_t)gemm_x3_want_slices(b, n, slots) * b * n *
                       sizeof(float), 256) +                       // split-K slabs
+         align_up(kSubStateWords * sizeof(unsigned), 256) +       // f16 scales
          256;
 }
 
@@ -363,7 +369,11 @@ extern "C" int vtc_subspace_ista_fista(
                       sparsity_weight, num_iters, variant, VTC_SOFT, precision,
                       workspace, workspace_bytes, iters_run,
                       as_stream(stream));
-  if (precision == VTC_F16X3) precision = VTC_BF16X3;   // tiled path
+  // tiled path: the f16 split (scaled units, x3_scale.h) runs where the
+  // proximal step is fused into the gradient product's epilogue; the other
+  // group shapes take the bf16 split
+  bool f16 = (precision == VTC_F16X3);
+  if (f16) precision = VTC_BF16X3;
   if (!workspace || workspace_bytes < subspace_ws_bytes(b, n, slots)) {
     set_error("vtc_subspace_ista_fista: workspace too small");
     return VTC_ERR_WORKSPACE;
@@ -381,6 +391,7 @@ extern "C" int vtc_subspace_ista_fista(
                             : 1;
   float* slabs = ws.take<float>((size_t)gemm_x3_want_slices(b, n, slots) * b * n);
   double* delta_sum = ws.take<double>(1);
+  unsigned* state = ws.take<unsigned>(kSubStateWords);
   const float eta = stepsize;
   const float cutoff = sparsity_weight * stepsize;
   const float eps = early_stopping_epsilon;
@@ -396,6 +407,30 @@ extern "C" int vtc_subspace_ista_fista(
     }
     int rc = launch_transpose(grouped_dictionary, DgT, slots, n, st);
     if (rc != VTC_OK) return rc;
+  }
+  {
+    const bool wide = slots % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(grouped_codes) & 15) == 0;
+    const bool pow2 = m == 1 || m == 2 || m == 4 || m == 8 || m == 16 ||
+                      m == 32;
+    f16 = f16 && x3 && wide && pow2;
+  }
+  float* dscale = f16 ? reinterpret_cast<float*>(state) : nullptr;
+  unsigned* y_slot[2] = {state + 64, state + 64 + kCxMaxSlotWords};
+  unsigned* r_slot[2] = {state + 64 + 2 * kCxMaxSlotWords,
+                         state + 64 + 3 * kCxMaxSlotWords};
+  if (f16) {
+    VTC_HIP_CHECK(hipMemsetAsync(state, 0, kSubStateWords * sizeof(unsigned),
+                                 st));
+    hipLaunchKernelGGL(cx_array_scale_kernel, dim3(1), dim3(1024), 0, st,
+                       grouped_dictionary, slots * n, dscale);
+    VTC_LAUNCH_CHECK();
+    if (initial_grouped) {
+      hipLaunchKernelGGL(cx_array_max_kernel, dim3(1024), dim3(256), 0, st,
+                         initial_grouped, b * slots, y_slot[0]);
+      VTC_LAUNCH_CHECK();
+    }
   }
   const bool fista = (variant == VTC_FISTA);
   const size_t bytes = (size_t)b * slots * sizeof(float);
@@ -413,16 +448,27 @@ extern "C" int vtc_subspace_ista_fista(
   int done = 0;
   for (int k = 0; k < num_iters; ++k) {
     EpiMinus e1{R, images, n, n};
+    // f16 split: see run_generic (fc_inference.hip)
+    X3Scale sc1, sc2;
+    if (f16) {
+      sc1.b_scale = sc2.b_scale = dscale;
+      sc1.a_max = y_slot[k & 1];
+      sc1.clear = y_slot[(k + 1) & 1];
+      sc2.a_max = r_slot[k & 1];
+      sc2.clear = r_slot[(k + 1) & 1];
+      e1.max_out = r_slot[k & 1];
+    }
     int rc;
     if (x3 && k1_slices > 1) {
       // few output tiles (n is small): split the long slot axis over blocks
       EpiSlab es{slabs, b * n, n};
       rc = launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, es, st,
-                          k1_slices);
+                          k1_slices, sc1);
       if (rc == VTC_OK)
-        rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st);
+        rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st,
+                                      f16 ? r_slot[k & 1] : nullptr);
     } else if (x3) {
-      rc = launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, e1, st);
+      rc = launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, e1, st, 1, sc1);
     } else {
       rc = launch_gemm_f32<true, false>(Y, slots, grouped_dictionary, n, b, n,
                                         slots, 1, e1, st);
@@ -442,7 +488,8 @@ extern "C" int vtc_subspace_ista_fista(
   case MM:                                                                  \
     rc = launch_grad_prox<MM>(x3, R, grouped_dictionary, Y, Cin, Yout,     \
                                  Cout, b, slots, n, eta, cutoff, beta_k,    \
-                                 fista ? 1 : 0, dsum, st);                  \
+                                 fista ? 1 : 0, dsum, st, sc2,              \
+                                 f16 ? y_slot[(k + 1) & 1] : nullptr);      \
     fused_prox = true;                                                      \
     break;
       switch (m) {
