@@ -854,8 +854,12 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     *rs = 1.f;
     *eta_eff = pp.eta;
     if (F16 && it.valid) {
+      // a SCALAR load (wave-uniform index): a vector load here would be the
+      // youngest vector-memory operation of the wave, and waiting for it
+      // would drain every code-map access in flight
+      const int img_u = __builtin_amdgcn_readfirstlane(it.img);
       float inv_r;
-      cx_scale_of_bits(sc.r_in[it.img], rs, &inv_r);
+      cx_scale_of_bits(sc.r_in[img_u], rs, &inv_r);
       *eta_eff = pp.eta * (inv_r * inv_d);
     }
   };
@@ -1147,6 +1151,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     // item ago -- the one full wait on memory per item costs nothing here.
     window_store(buf ^ 1, rs_nxt);
     const CxItem nn = decode(rank + (i + 2) * nper);
+    float rs_nn, eta_nn;                             // used two items from now
+    item_scale(nn, &rs_nn, &eta_nn);
     if (row_ok) {
       f32x16 acc[2];
 #pragma unroll
@@ -1183,21 +1189,23 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       // then stores, then the loads of the next item into the freed registers
       // (most of an item of work between their issue and their use).
       prox_tile(cur, 0, yA, cA, acc[0]);
-      if (do_synth && !F16) synth_tile(0, acc[0], 1.f);
-      prox_tile(cur, 1, yB, cB, acc[1]);
-      // F16: one power of two per code column (= lane, both halves) from the
-      // 64 values of the column this wave holds
-      float col_scale = 1.f, col_unscale = 1.f;
-      if (F16 && do_synth) {
+      // F16: one power of two per code column (= lane, both halves) and atom
+      // tile, from the 32 values of the column in that tile; the tap sums are
+      // carried from the first tile's scale to the second's (a power of two,
+      // exact) and scaled back after it
+      float col_s0 = 1.f, col_u0 = 1.f;
+      auto column_scale = [&](const f32x16& t, float* cs, float* cu) {
         float m = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          m = fmaxf(m, fmaxf(fabsf(acc[0][r]), fabsf(acc[1][r])));
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(t[r]));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        cx_scale_of_bits(__float_as_uint(m), &col_scale, &col_unscale);
-        col_unscale *= inv_d;
-        synth_tile(0, acc[0], col_scale);
+        cx_scale_of_bits(__float_as_uint(m), cs, cu);
+      };
+      if (do_synth) {
+        if (F16) column_scale(acc[0], &col_s0, &col_u0);
+        synth_tile(0, acc[0], col_s0);
       }
+      prox_tile(cur, 1, yB, cB, acc[1]);
       if (pp.delta_sum) {
         const double w = wave_sum((double)stop_sum);
         if (lane == 0) atomicAdd(pp.delta_sum, w);
@@ -1210,12 +1218,24 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       load_tile(nxt, 0, yA, cA);
       load_tile(nxt, 1, yB, cB);
       stamp(8);
-      if (do_synth) synth_tile(1, acc[1], col_scale);
-      if (F16 && do_synth) {
+      if (do_synth) {
+        float col_s1 = 1.f, col_u1 = 1.f;
+        if (F16) {
+          column_scale(acc[1], &col_s1, &col_u1);
+          const float carry = col_s1 * col_u0;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Q[mt][r] *= col_unscale;
+            for (int r = 0; r < 16; ++r) Q[mt][r] *= carry;
+        }
+        synth_tile(1, acc[1], col_s1);
+        if (F16) {
+          const float back = col_u1 * inv_d;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Q[mt][r] *= back;
+        }
       }
       stamp(3);
       if (do_synth) fold(Priv + (buf * F::ROWS + wave) * K * WP);
@@ -1251,7 +1271,8 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
     nxt = nn;
     rs_cur = rs_nxt;
     eta_cur = eta_nxt;
-    item_scale(nxt, &rs_nxt, &eta_nxt);
+    rs_nxt = rs_nn;
+    eta_nxt = eta_nn;
   }
   if (STAMP && lane == 0) {
     for (int q = 0; q < 9; ++q) atomicAdd(stamps + q, st_acc[q]);
