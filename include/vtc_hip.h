@@ -22,7 +22,9 @@
  *                                                                        vtc_group_norm_sum, vtc_window_minmax,
  *                                                                        vtc_rows_mean_abs_diff
  *   utils/image_processing.py:267-308, utils/dataset_generation.py
- *     :184-222 (whitening, patch extraction)                          -> vtc_whiten_center_surround, vtc_extract_patches
+ *     :169-222 (range standardisation, whitening, patch positions
+ *     and extraction)                                                 -> vtc_standardize_data_range, vtc_whiten_center_surround,
+ *                                                                        vtc_draw_patch_positions, vtc_extract_patches
  *   dict_update_rules/fully_connected/ica_natural_gradient.py:6-35    -> vtc_ica_moment, vtc_ica_apply
  *
  * Conventions
@@ -322,13 +324,35 @@ int vtc_rows_mean_abs_diff(const float* a, const float* b, int64_t rows,
  * (count, h, w, c) float32 as in the reference. */
 size_t vtc_whiten_center_surround_workspace_bytes(int64_t count, int32_t h,
                                                   int32_t w, int32_t c);
-/* norm_and_threshold must be 0 (the dataset pipeline's setting); 1 returns
- * VTC_ERR_UNSUPPORTED */
+/* norm_and_threshold != 0 (the reference function's default,
+ * image_processing.py:302-304): the transfer function is divided by its
+ * maximum over the frequency grid and values below 1e-3 are raised to 1e-3;
+ * 0 is what the dataset pipeline passes (dataset_generation.py:231-238) */
 int vtc_whiten_center_surround(const float* images, float* out, int64_t count,
                                int32_t h, int32_t w, int32_t c,
                                float cutoff_low, float cutoff_high,
                                int norm_and_threshold, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* 'standardize_data_range' of utils/dataset_generation.py:169-183, the first
+ * operation of every example pipeline: out = (images - min) / (max - min)
+ * over the whole array (count floats, any shape), float32 arithmetic as
+ * numpy's.  min_max (device, 2 floats) receives [min, max]; the reference
+ * asserts max > min, a caller reads them back for that.  workspace:
+ * vtc_window_minmax_workspace_bytes(). */
+int vtc_standardize_data_range(const float* images, float* out, int64_t count,
+                               float* min_max, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* HOST-side helper (no device work): the patch positions of
+ * utils/dataset_generation.py:205-214 -- per patch np.random.randint(0,
+ * num_images), randint(edge_buffer, max_vert[image]), randint(edge_buffer,
+ * max_horz[image]), in that order -- drawn from numpy's legacy generator
+ * state: key (624 words) and *pos are RandomState.get_state()[1:3], updated
+ * in place.  img_index / vert / horz: num_samples int32 each, host memory.
+ * 131 072 positions take ~2 ms; the reference's Python loop 0.3-0.4 s. */
+int vtc_draw_patch_positions(uint32_t* key, int32_t* pos, int64_t num_samples,
+                             int32_t num_images, int32_t edge_buffer,
+                             const int32_t* max_vert, const int32_t* max_horz,
+                             int32_t* img_index, int32_t* vert, int32_t* horz);
 /* patches (num, ph*pw*c): patch p = images[img_index[p],
  * vert[p]:vert[p]+ph, horz[p]:horz[p]+pw, :] flattened; positions come from
  * the caller's random number generator (int32 device arrays) */

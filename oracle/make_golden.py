@@ -784,12 +784,19 @@ def make_whitened(ref):
   white = [ref.image_processing.whiten_center_surround(
       im[:, :, None], cutoffs={'low': 1e-3, 'high': 0.9},
       norm_and_threshold=False)[:, :, 0] for im in imgs]
-  patches = []
-  for w in white:
+  # the reference function's own default, norm_and_threshold=True (transfer
+  # function divided by its maximum, floored at 1e-3): same positions
+  white_nat = [ref.image_processing.whiten_center_surround(
+      im[:, :, None], cutoffs={'low': 1e-3, 'high': 0.9})[:, :, 0]
+               for im in imgs]
+  patches, patches_nat = [], []
+  for w, wn in zip(white, white_nat):
     for _ in range(64):
       y, x = rs.randint(5, size - 21, size=2)
       patches.append(np.asarray(w)[y:y + 16, x:x + 16].reshape(-1))
+      patches_nat.append(np.asarray(wn)[y:y + 16, x:x + 16].reshape(-1))
   X = np.stack(patches).astype(np.float32)
+  X_nat = np.stack(patches_nat).astype(np.float32)
   D = unit_rows(51, 512, 256)
   lam = 0.008
   codes = ref.fc_inf.run(T(X), T(D), lam, 100, variant='fista')
@@ -798,7 +805,8 @@ def make_whitened(ref):
   print('   whitened patches: std %.4f, non-zero fraction %.3f'
         % (X.std(), float((codes != 0).float().mean())))
   np.savez_compressed(
-      GOLDEN / 'whitened.npz', images=X, seed_dictionary=51,
+      GOLDEN / 'whitened.npz', images=X, images_norm_and_threshold=X_nat,
+      seed_dictionary=51,
       sparsity_weight=np.float32(lam),
       stepsize=np.float32(ref_eta_fc(T(D))), codes_fista_T100=codes.numpy())
 

@@ -328,3 +328,40 @@ def test_checkpoint_loader_reads_arrays_only(tmp_path):
     pickle.dump(Evil(), f)
   with pytest.raises(pickle.UnpicklingError):
     trainer.load_newest_dictionary_checkpoint(tmp_path)
+
+
+def test_native_position_draw_equals_the_reference_loop():
+  """draw_patch_positions (one native call on numpy's MT19937 state) gives the
+  numbers of the reference's three-randint-per-patch loop
+  (dataset_generation.py:205-214) and leaves the generator where the loop
+  leaves it: equal image sizes, one image (randint over a single value draws
+  nothing), ragged image sizes, ranges with heavy rejection, the global
+  generator; and it is fast enough not to stall a training step."""
+  import time
+  from utils import dataset_generation as dg
+  cases = [((512, 512), 10, (16, 16), 5), ((512, 512), 1, (16, 16), 5),
+           ([(100, 120), (64, 300), (257, 90)], 3, (8, 8), 0),
+           ((16 + 2 * 4 + 129, 16 + 2 * 4 + 2), 33, (16, 16), 4)]
+  for shapes, count, patch, edge in cases:
+    a, b = np.random.RandomState(5), np.random.RandomState(5)
+    fast = dg.draw_patch_positions(5000, shapes, patch, edge, count, rng=a)
+    slow = dg.draw_patch_positions_loop(5000, shapes, patch, edge, count,
+                                        rng=b)
+    for x, y in zip(fast, slow):
+      assert x.dtype == np.int32 and np.array_equal(x, y)
+    assert a.randint(0, 1 << 30) == b.randint(0, 1 << 30)
+    assert a.standard_normal() == b.standard_normal()
+  np.random.seed(11)
+  fast = dg.draw_patch_positions(3000, (64, 64), (16, 16), 2, 7)
+  after_fast = np.random.randint(0, 1 << 30)
+  np.random.seed(11)
+  slow = dg.draw_patch_positions_loop(3000, (64, 64), (16, 16), 2, 7)
+  assert np.random.randint(0, 1 << 30) == after_fast
+  assert all(np.array_equal(x, y) for x, y in zip(fast, slow))
+  rng = np.random.RandomState(1)
+  dg.draw_patch_positions(1000, (512, 512), (16, 16), 5, 40, rng=rng)  # warm
+  t0 = time.perf_counter()
+  dg.draw_patch_positions(131072, (512, 512), (16, 16), 5, 40, rng=rng)
+  assert time.perf_counter() - t0 < 0.05    # ~2-3 ms; the loop takes 0.3-0.4 s
+  with pytest.raises(ValueError):             # an image smaller than a patch
+    dg.draw_patch_positions(4, (20, 20), (16, 16), 5, 2, rng=rng)

@@ -47,9 +47,18 @@ def test_whitened_patches_match_reference(device):
   # float64 transform then a cast to float32 on both sides: 1e-6 relative
   assert patches.shape == g['images'].shape
   assert helpers.rel_err(patches.cpu().numpy(), g['images']) < 1e-6
+  # the reference function's default, norm_and_threshold=True: transfer
+  # function divided by its maximum over the grid, floored at 1e-3
+  white_nat = image_processing.whiten_center_surround(
+      dev_imgs, {'low': 1e-3, 'high': 0.9})
+  patches = dataset_generation.extract_patches(white_nat, idx, vert, horz,
+                                               (16, 16))
+  assert helpers.rel_err(patches.cpu().numpy(),
+                         g['images_norm_and_threshold']) < 1e-6
   with pytest.raises(NotImplementedError):
     image_processing.whiten_center_surround(dev_imgs, {'low': 1e-3,
-                                                       'high': 0.9})
+                                                       'high': 0.9},
+                                            return_filter=True)
   with pytest.raises(IndexError):
     dataset_generation.extract_patches(white, [0], [120], [0], (16, 16))
 
@@ -71,3 +80,20 @@ def test_patch_extraction_layout_and_channels(device):
     assert idx[p] == rng.randint(low=0, high=3)
     assert vert[p] == rng.randint(low=2, high=20 - 5 - 2)
     assert horz[p] == rng.randint(low=2, high=31 - 7 - 2)
+
+
+def test_standardize_data_range(device):
+  """dataset_generation.py:169-183: (x - min) / (max - min) over the whole
+  stack in float32, bit for bit numpy's; a constant stack trips the
+  reference's assert."""
+  from utils import dataset_generation
+  rs = np.random.RandomState(4)
+  imgs = (255.0 * rs.rand(3, 37, 53, 2)).astype(np.float32) - 17.0
+  lo, hi = np.min(imgs), np.max(imgs)
+  want = (imgs - lo) / (hi - lo)
+  got = dataset_generation.standardize_data_range(helpers.to_dev(imgs, device))
+  assert got.shape == imgs.shape and np.array_equal(got.cpu().numpy(), want)
+  assert float(got.min()) == 0.0 and float(got.max()) == 1.0
+  with pytest.raises(AssertionError):
+    dataset_generation.standardize_data_range(
+        torch.full((4, 4), 2.5, device=device))

@@ -19,9 +19,11 @@ def whiten_center_surround(image, cutoffs, return_filter=False,
       stack (count, h, w, c) of equally sized images (an extension: one
       batched transform).
   cutoffs : {'low': ..., 'high': ...} as in the reference.
-  Returns the filtered image(s), same shape.  return_filter=True and
-  norm_and_threshold=True are not implemented on the device (the dataset
-  pipeline, dataset_generation.py:231-238, uses neither).
+  norm_and_threshold : as in the reference (default True: the transfer
+      function is divided by its maximum and floored at 1e-3; the dataset
+      pipeline, dataset_generation.py:231-238, passes False).
+  Returns the filtered image(s), same shape.  return_filter=True is host-side
+  debugging output and not implemented on the device.
   """
   if return_filter:
     raise NotImplementedError('return_filter is host-side debugging output')

@@ -98,6 +98,9 @@ SIGNATURES = {
                                           _f32, _f32, _i32, _vp, _sz, _vp]),
     'vtc_extract_patches': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
                                    _i32, _i32, _i32, _vp]),
+    'vtc_standardize_data_range': (_i32, [_vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    'vtc_draw_patch_positions': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp,
+                                        _vp, _vp, _vp]),
     'vtc_ica_moment_workspace_bytes': (_sz, [_i64, _i64]),
     'vtc_ica_moment': (_i32, [_vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     'vtc_ica_apply_workspace_bytes': (_sz, [_i64, _i64]),
