@@ -365,3 +365,42 @@ def test_native_position_draw_equals_the_reference_loop():
   assert time.perf_counter() - t0 < 0.05    # ~2-3 ms; the loop takes 0.3-0.4 s
   with pytest.raises(ValueError):             # an image smaller than a patch
     dg.draw_patch_positions(4, (20, 20), (16, 16), 5, 2, rng=rng)
+
+
+def test_wide_buffer_stores_keep_a_constant_scalar_offset():
+  """Source guard for a gfx950 / ROCm 7.2 code-generation hazard found in
+  round 3 (csrc/epi_prox.h): a 12- or 16-byte buffer store whose scalar-offset
+  operand is a register gets no wait state before a VALU instruction
+  overwrites its data registers, and the store can then write the NEW value
+  in a few lanes.  Every such store in the library passes its offsets through
+  the vector offset and the constant 0 as the scalar offset."""
+  import pathlib
+  import re
+  csrc = pathlib.Path(__file__).resolve().parent.parent / (
+      'vision-transform-codes_amd') / 'csrc'
+  call = re.compile(
+      r'__builtin_amdgcn_raw(?:_ptr)?_buffer_store_b(?:96|128)\s*\(')
+  found = 0
+  for path in sorted(csrc.glob('*.h')) + sorted(csrc.glob('*.hip')):
+    text = path.read_text()
+    for m in call.finditer(text):
+      depth, i, args, cur = 1, m.end(), [], ''
+      while depth:
+        ch = text[i]
+        if ch == '(':
+          depth += 1
+        elif ch == ')':
+          depth -= 1
+          if depth == 0:
+            break
+        if ch == ',' and depth == 1:
+          args.append(cur.strip())
+          cur = ''
+        else:
+          cur += ch
+        i += 1
+      args.append(cur.strip())
+      found += 1
+      assert len(args) == 5 and args[3] == '0', (
+          '%s: wide buffer store with scalar offset %r' % (path.name, args[3]))
+  assert found >= 3

@@ -213,6 +213,33 @@ def test_full_size_properties(device, plugins):
                              max_flip_mag=5e-6)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'f16x3'])
+def test_saturated_memory_pipeline_is_reproducible(device, plugins, precision):
+  """20 000 patches x 300 slots (rows that are not multiples of 128 bytes,
+  enough blocks to keep the memory pipeline busy): two runs are bit-identical
+  and agree with the exact-f32 path.  This is the size at which a 16-byte
+  buffer store with a register scalar offset lost its first element in a few
+  lanes (a wait state hipcc leaves out on gfx950; csrc/epi_prox.h) -- small
+  problems never showed it."""
+  sub = plugins[0]
+  rs = np.random.RandomState(0)
+  m, num_groups, n, b = 4, 75, 144, 20000
+  X = helpers.to_dev((0.1 * rs.randn(b, n)).astype(np.float32), device)
+  D = helpers.to_dev(helpers.unit_rows(103, num_groups * m, n), device)
+  groups = [list(range(g * m, g * m + m)) for g in range(num_groups)]
+  runs = [sub.run(X, D, groups, 0.01, 3, stepsize=0.05, precision=precision)
+          for _ in range(4)]
+  for other in runs[1:]:
+    assert torch.equal(runs[0], other)
+  exact = runs[0] if precision == 'f32' else sub.run(
+      X, D, groups, 0.01, 3, stepsize=0.05, precision='f32')
+  helpers.assert_codes_match(
+      runs[0].cpu().numpy(), exact.cpu().numpy(),
+      2e-5 if precision == 'bf16x3' else helpers.REL_TOL_SHORT,
+      'large batch ' + precision,
+      max_flip_mag=1e-5 if precision == 'bf16x3' else helpers.NEAR_THRESHOLD)
+
+
 def test_empty_batch(device, plugins):
   sub = plugins[0]
   D = helpers.to_dev(helpers.unit_rows(3, 16, 32), device)

@@ -59,3 +59,21 @@ for prec in ('f16x3', 'bf16x3'):
 codes = ista_fista.run(X, D, lam, 50, variant='ista', precision='f32',
                        stepsize=eta)
 row('f32    ISTA T=50', codes, g['codes_ista_T50'])
+
+# the tiled contractions (shapes outside the fused kernels): 20x20 patches, 500
+# atoms, against the CPU oracle (bit-identical to the reference on every
+# fixture; there is no reference fixture at this shape)
+sys.path.insert(0, os.path.join(REPO, 'oracle'))
+import sc_oracle
+Xn = helpers.gaussian_patches(81, 96, 400)
+Dn = helpers.unit_rows(82, 500, 400)
+eta_n = sc_oracle.fc_stepsize(torch.from_numpy(Dn))
+print('tiled contractions, 96 x 400 patches, 500 atoms, lambda 0.02, distance '
+      'from the oracle')
+for T in (30, 200):
+  ref = sc_oracle.fc_ista_fista(torch.from_numpy(Xn), torch.from_numpy(Dn),
+                                0.02, T, stepsize=eta_n).numpy()
+  for prec in ('f32', 'f16x3', 'bf16x3'):
+    codes = ista_fista.run(helpers.to_dev(Xn, dev), helpers.to_dev(Dn, dev),
+                           0.02, T, precision=prec, stepsize=float(eta_n))
+    row('%-6s T=%-3d tiled n=400' % (prec, T), codes, ref)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of a round on the MI355X box into gpurun_out/$1/.
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -39,6 +39,10 @@ python3 tools/pmc_summary.py $out conv_ > $out/conv_pmc.txt; cat $out/conv_pmc.t
 VTC_CONV_STAMPS=1 timeout -k 10 100 python3 tools/run_configs.py conv 2>&1 | grep -A10 "do_synth=1" | tail -11 > $out/conv_stamps.txt; cat $out/conv_stamps.txt
 [ -x tools/micro/lds_unaligned ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/lds_unaligned.hip -o tools/micro/lds_unaligned 2>/dev/null
 timeout -k 10 60 tools/micro/lds_unaligned > $out/lds_unaligned.txt 2>&1; cat $out/lds_unaligned.txt
+[ -x tools/peaks/peaks ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/peaks/peaks.hip -o tools/peaks/peaks 2>/dev/null
+timeout -k 10 120 tools/peaks/peaks > $out/peaks.txt 2>&1; grep -i "HBM\|MFMA\|stream" $out/peaks.txt
+timeout -k 10 300 python3 tools/precision_conv_report.py 2>&1 | grep -v amdgpu > $out/precision_conv.txt; tail -8 $out/precision_conv.txt
+timeout -k 10 300 python3 tools/precision_report.py 2>&1 | grep -v amdgpu > $out/precision_fc.txt; tail -12 $out/precision_fc.txt
 echo "== fully-connected shapes outside the headline kernel, reproducibility soak"
 timeout -k 10 300 python3 tools/time_fc_shapes.py 2>&1 | grep -v amdgpu > $out/fc_other_shapes.txt; cat $out/fc_other_shapes.txt
 timeout -k 10 600 python3 tools/soak_reproducibility.py 150 2>&1 | grep -v amdgpu > $out/soak_reproducibility.txt; tail -2 $out/soak_reproducibility.txt

@@ -44,7 +44,7 @@ total = 0
 rs = np.random.RandomState(0)
 # fully-connected, tiled paths (s % 32 != 0: rows of codes share cache lines)
 for n, s, b, prec in ((144, 100, 20000, 'f32'), (144, 580, 20000, 'bf16x3'),
-                      (64, 36, 60000, 'f32')):
+                      (144, 580, 20000, 'f16x3'), (64, 36, 60000, 'f32')):
   X = torch.from_numpy((0.1 * rs.randn(b, n)).astype(np.float32)).to(dev)
   D = rows(n + s, s, n)
   for variant in ('fista', 'ista'):
@@ -52,7 +52,8 @@ for n, s, b, prec in ((144, 100, 20000, 'f32'), (144, 580, 20000, 'bf16x3'),
                   lambda: ista_fista.run(X, D, 0.01, 12, variant=variant,
                                          stepsize=0.05, precision=prec))
 # subspace: fused epilogue (groups of 4) and separate prox (groups of 3)
-for m, G, prec in ((4, 75, 'bf16x3'), (3, 100, 'f32'), (3, 100, 'bf16x3')):
+for m, G, prec in ((4, 75, 'bf16x3'), (4, 75, 'f16x3'), (3, 100, 'f32'),
+                   (3, 100, 'bf16x3')):
   n, b = 144, 20000
   s = G * m
   X = torch.from_numpy((0.1 * rs.randn(b, n)).astype(np.float32)).to(dev)
@@ -69,6 +70,8 @@ for m, G, prec in ((4, 75, 'bf16x3'), (3, 100, 'f32'), (3, 100, 'bf16x3')):
 for k, s, stride, prec, label in ((11, 24, 1, 'f32', 'f32 unit-stride'),
                                   (16, 40, 1, 'bf16x3', 'bf16x3 two kernels'),
                                   (11, 128, 1, 'bf16x3', 'bf16x3 fused'),
+                                  (16, 40, 1, 'f16x3', 'f16x3 two kernels'),
+                                  (11, 128, 1, 'f16x3', 'f16x3 fused'),
                                   (16, 32, 8, 'f32', 'f32 patch route')):
   img, b = 200, 4
   pad = k - 1 if stride == 1 else 8
@@ -97,6 +100,14 @@ def upd():
   return D
 
 
+total += soak('FC cheap-quadratic update n=%d s=%d' % (n, s), upd)
+# odd pixel count: rows of 121 floats never end on a 128-byte line, the apply
+# kernel's blocks own 32 rows (the smallest footprint that does)
+n, s, b = 121, 1000, 20000
+X = torch.from_numpy((0.1 * rs.randn(b, n)).astype(np.float32)).to(dev)
+D0 = rows(6, s, n)
+C = ista_fista.run(X, D0, 0.01, 12, stepsize=0.05, precision='f32')
+h = torch.full((s,), 0.01, device=dev)
 total += soak('FC cheap-quadratic update n=%d s=%d' % (n, s), upd)
 print('TOTAL differing runs:', total)
 sys.exit(1 if total else 0)

@@ -1033,8 +1033,11 @@ __global__ __launch_bounds__(512) void conv_fused_x3_kernel(
       cx_u32x4 c4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) c4[j] = __float_as_uint(cv[4 * k4 + j]);
-      __builtin_amdgcn_raw_buffer_store_b128(c4, ors, lane16 + 1024u * k4, blk,
-                                             0);
+      // block offset in the vector offset, scalar offset 0: with a register
+      // there hipcc leaves out the wait state a 16-byte store needs before a
+      // VALU instruction overwrites its data registers (epi_prox.h)
+      __builtin_amdgcn_raw_buffer_store_b128(c4, ors,
+                                             lane16 + 1024u * k4 + blk, 0, 0);
     }
   };
   f32x16 Q[MT];

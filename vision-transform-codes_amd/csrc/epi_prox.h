@@ -12,7 +12,25 @@ namespace vtc {
 // adjacent columns, i.e. m adjacent lanes of the accumulator tile, so the
 // group norm is a lane-shuffle tree and the (b, slots) state is read and
 // written once per iteration instead of three times.
-template <int M, bool ELEMENTWISE = false>
+// f16 split of the next product (x3_scale.h): TRACK adds the slot that
+// receives the maximum of the new iterate |Y'| (a separate instantiation: the
+// functors of the other paths stay as they were)
+template <bool TRACK>
+struct EpiMaxTrack {
+  __device__ __forceinline__ void note(float) {}
+  __device__ __forceinline__ void publish() const {}
+};
+template <>
+struct EpiMaxTrack<true> {
+  unsigned* max_out = nullptr;
+  float mx = 0.f;
+  __device__ __forceinline__ void note(float v) { mx = fmaxf(mx, fabsf(v)); }
+  __device__ __forceinline__ void publish() const {
+    if (max_out) cx_publish_max_wave(mx, max_out);
+  }
+};
+
+template <int M, bool ELEMENTWISE = false, bool TRACK = false>
 struct EpiGroupProx {
   static constexpr bool kWholeTile = true;
   static constexpr int kPrefetch = 32;     // 16 of Y + 16 of the codes
@@ -36,10 +54,7 @@ struct EpiGroupProx {
   // (their L2s are not coherent within a launch).
   float* Yo = nullptr;
   float* Co = nullptr;
-  // f16 split of the next product (x3_scale.h): the slot that receives the
-  // maximum of the new iterate |Y'|
-  unsigned* max_out = nullptr;
-  float mx = 0.f;
+  EpiMaxTrack<TRACK> track;
   __device__ __forceinline__ void resolve() {
     if (eta_dev) {
       eta = *eta_dev;
@@ -163,13 +178,22 @@ struct EpiGroupProx {
         const float yn = fista ? add_rn(cn, mul_rn(beta, d)) : cn;
         y4[i] = __float_as_uint(yn);
         c4[i] = __float_as_uint(cn);
-        mx = fmaxf(mx, fabsf(yn));
+        track.note(yn);
         if (delta_sum) local += (double)(fabsf(d) / eta);
       }
-      __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yws, off,
-                                             (unsigned)(8 * q) * ld4, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(c4, ctx.cws, off,
-                                             (unsigned)(8 * q) * ld4, 0);
+      // The row offset goes into the VECTOR offset, the scalar offset stays
+      // the constant 0.  With a register in the scalar-offset field hipcc
+      // (ROCm 7.2) treats a 16-byte buffer store as free of the "VALU
+      // overwrites store data" hazard and puts no wait state behind it; on
+      // gfx950 the hazard is there: `buffer_store_dwordx4 v[26:29], ..., s77
+      // offen` followed at once by `v_fma_f32 v26, ...` stored the NEW v26 in
+      // a few lanes, when the memory pipeline was busy (found by the bitwise
+      // soak: ~0.03 % of the codes, first element of a 16-byte piece, run to
+      // run different).  An out-of-range lane offset (0x80000000) stays out
+      // of range with the row offset added.
+      const unsigned row_off = off + (unsigned)(8 * q) * ld4;
+      __builtin_amdgcn_raw_buffer_store_b128(y4, ctx.yws, row_off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(c4, ctx.cws, row_off, 0, 0);
     }
   }
   __device__ __forceinline__ void operator()(int64_t, int64_t, float,
@@ -179,7 +203,7 @@ struct EpiGroupProx {
       const double w = wave_sum(local);
       if ((threadIdx.x & 63) == 0) atomicAdd(delta_sum, w);
     }
-    if (max_out) cx_publish_max_wave(mx, max_out);
+    track.publish();
   }
 };
 

@@ -183,7 +183,6 @@ static int run_generic(const float* images, const float* dictionary,
       sc1.clear = y_slot[(k + 1) & 1];
       sc2.a_max = r_slot[k & 1];
       sc2.clear = r_slot[(k + 1) & 1];
-      e1.max_out = r_slot[k & 1];
     }
     int rc;
     if (x3 && k1_slices > 1) {
@@ -192,6 +191,9 @@ static int run_generic(const float* images, const float* dictionary,
       if (rc == VTC_OK)
         rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st,
                                       f16 ? r_slot[k & 1] : nullptr);
+    } else if (x3 && f16) {
+      EpiMinusMax e1m{R, images, n, n, r_slot[k & 1]};
+      rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, e1m, st, 1, sc1);
     } else if (x3) {
       rc = launch_gemm_x3(Y, s, Dt, s, b, n, s, e1, st, 1, sc1);
     } else {
@@ -214,10 +216,20 @@ static int run_generic(const float* images, const float* dictionary,
                                threshold, eta_dev, lam};
       e2.Yo = fista ? Yout : Cout;
       e2.Co = Cout;
-      if (f16) e2.max_out = y_slot[(k + 1) & 1];
-      rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st, 1, sc2)
-              : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
-                                            e2, st);
+      if (f16) {
+        EpiGroupProx<1, true, true> e2t{Y, Cin, s, eta, cutoff,
+                                        fista ? betas[k] : 0.f, fista ? 1 : 0,
+                                        eps >= 0.f ? delta_sum : nullptr, 0.0,
+                                        threshold, eta_dev, lam};
+        e2t.Yo = e2.Yo;
+        e2t.Co = e2.Co;
+        e2t.track.max_out = y_slot[(k + 1) & 1];
+        rc = launch_gemm_x3(R, n, dictionary, n, b, s, n, e2t, st, 1, sc2);
+      } else {
+        rc = x3 ? launch_gemm_x3(R, n, dictionary, n, b, s, n, e2, st, 1, sc2)
+                : launch_gemm_f32<true, true>(R, n, dictionary, n, b, s, n, 1,
+                                              e2, st);
+      }
     } else {
       EpiProx e2{Y, Cin, s, eta, cutoff, fista ? betas[k] : 0.f, threshold,
                  fista ? 1 : 0, eps >= 0.f ? delta_sum : nullptr, 0.0,

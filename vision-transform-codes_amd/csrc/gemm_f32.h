@@ -395,8 +395,20 @@ struct EpiMinus {  // C = acc - X   (the reconstruction residual)
   float* C;
   const float* X;
   int64_t ldc, ldx;
-  // f16 split of the NEXT product (x3_scale.h): the slot that receives max |C|
-  unsigned* max_out = nullptr;
+  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
+                                             int) const {
+    C[row * ldc + col] = sub_rn(v, X[row * ldx + col]);
+  }
+  __device__ __forceinline__ void block_end() const {}
+};
+
+// the same, leaving max |C| in a slot for the f16 split of the next product
+// (x3_scale.h)
+struct EpiMinusMax {
+  float* C;
+  const float* X;
+  int64_t ldc, ldx;
+  unsigned* max_out;
   float mx = 0.f;
   __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
                                              int) {
@@ -405,7 +417,7 @@ struct EpiMinus {  // C = acc - X   (the reconstruction residual)
     mx = fmaxf(mx, fabsf(r));
   }
   __device__ __forceinline__ void block_end() const {
-    if (max_out) cx_publish_max_wave(mx, max_out);
+    cx_publish_max_wave(mx, max_out);
   }
 };
 

@@ -46,10 +46,17 @@ static int launch_grad_prox(bool x3, const float* R, const float* Dg, float* Y,
                             float beta, int fista, double* delta_sum,
                             hipStream_t st, X3Scale sc = X3Scale(),
                             unsigned* y_max_out = nullptr) {
+  if (y_max_out) {                 // f16 split: the new iterate's maximum too
+    EpiGroupProx<M, false, true> t{Y, C, slots, eta, cutoff, beta, fista,
+                                   delta_sum, 0.0, 0};
+    t.Yo = Yo;
+    t.Co = Co;
+    t.track.max_out = y_max_out;
+    return launch_gemm_x3(R, n, Dg, n, b, slots, n, t, st, 1, sc);
+  }
   EpiGroupProx<M> e{Y, C, slots, eta, cutoff, beta, fista, delta_sum, 0.0, 0};
   e.Yo = Yo;
   e.Co = Co;
-  e.max_out = y_max_out;
   return x3 ? launch_gemm_x3(R, n, Dg, n, b, slots, n, e, st, 1, sc)
             : launch_gemm_f32<true, true>(R, n, Dg, n, b, slots, n, 1, e, st);
 }
@@ -456,7 +463,6 @@ extern "C" int vtc_subspace_ista_fista(
       sc1.clear = y_slot[(k + 1) & 1];
       sc2.a_max = r_slot[k & 1];
       sc2.clear = r_slot[(k + 1) & 1];
-      e1.max_out = r_slot[k & 1];
     }
     int rc;
     if (x3 && k1_slices > 1) {
@@ -467,6 +473,9 @@ extern "C" int vtc_subspace_ista_fista(
       if (rc == VTC_OK)
         rc = launch_slab_reduce_minus(slabs, k1_slices, b * n, images, R, st,
                                       f16 ? r_slot[k & 1] : nullptr);
+    } else if (x3 && f16) {
+      EpiMinusMax e1m{R, images, n, n, r_slot[k & 1]};
+      rc = launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, e1m, st, 1, sc1);
     } else if (x3) {
       rc = launch_gemm_x3(Y, slots, DgT, slots, b, n, slots, e1, st, 1, sc1);
     } else {
