@@ -205,16 +205,17 @@ typedef struct vtc_conv_geometry {
 int vtc_conv_code_dims(const vtc_conv_geometry* g, int32_t* code_h,
                        int32_t* code_w);
 size_t vtc_conv_ista_fista_workspace_bytes(const vtc_conv_geometry* g);
-/* 1 when the geometry has a VTC_BF16X3 path: one channel, stride 1, square
- * kernels of 5, 8, 11 or 16, operand planes within the 160 KiB LDS. */
+/* 1 when the geometry has a split-precision (VTC_F16X3 / VTC_BF16X3) path:
+ * stride 1, square kernels of 5, 8, 11 or 16, operand planes within the
+ * 160 KiB LDS (1 to 3 image channels at 11x11 and 16x16). */
 int vtc_conv_x3_supported(const vtc_conv_geometry* g);
 /* images_padded (b,c,h,w), dictionary (s,c,kh,kw), codes (b,s,code_h,code_w).
  * precision: VTC_F32 (direct f32 convolutions, fixed summation order),
  * VTC_F16X3 or VTC_BF16X3 (both convolutions as hi/lo split MFMA
  * contractions, f16 in power-of-two scaled units or bf16;
  * VTC_ERR_UNSUPPORTED unless vtc_conv_x3_supported).  With kernels up to
- * 11x11 and more than 32 of them the split modes run one fused launch per
- * iteration (analysis, proximal step and the next residual) on code maps kept
+ * 11x11, more than 32 of them and one image channel the split modes run one
+ * fused launch per iteration (analysis, proximal step and the next residual) on code maps kept
  * in an internal tile order; the caller's layout is written by the last one. */
 int vtc_conv_ista_fista(const float* images_padded, const float* dictionary,
                         const float* initial_codes, float* codes,

@@ -180,13 +180,13 @@ def test_unit_stride_specialisations(device, plugins, k, c, s, height, width):
   assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
 
 
-def _conv_case(seed, k, s, height, width, b=2, scale=0.5):
+def _conv_case(seed, k, s, height, width, b=2, scale=0.5, c=1):
   rs = np.random.RandomState(seed)
   pad = k - 1
-  imgs = np.zeros((b, 1, height + 2 * pad, width + 2 * pad), np.float32)
+  imgs = np.zeros((b, c, height + 2 * pad, width + 2 * pad), np.float32)
   imgs[:, :, pad:pad + height, pad:pad + width] = (
-      scale * rs.randn(b, 1, height, width)).astype(np.float32)
-  D = rs.randn(s, 1, k, k).astype(np.float32)
+      scale * rs.randn(b, c, height, width)).astype(np.float32)
+  D = rs.randn(s, c, k, k).astype(np.float32)
   D /= np.sqrt((D.astype(np.float64) ** 2).sum(axis=(1, 2, 3)))[
       :, None, None, None].astype(np.float32)
   return imgs, D, ((pad, pad), (pad, pad))
@@ -199,7 +199,8 @@ def _conv_case(seed, k, s, height, width, b=2, scale=0.5):
                                               (11, 9, 64, 64),
                                               (5, 40, 41, 130),
                                               (8, 64, 50, 77),
-                                              (16, 20, 48, 80)])
+                                              (16, 20, 48, 80),
+                                              (16, 100, 30, 44)])
 def test_split_modes_matrix_core_path(device, plugins, k, s, height, width):
   """Stride-1 one-channel geometries with precision='f16x3' / 'bf16x3': both
   convolutions as hi/lo split MFMA contractions (conv_x3.h).  Tile-ragged
@@ -227,6 +228,70 @@ def test_split_modes_matrix_core_path(device, plugins, k, s, height, width):
       helpers.assert_codes_match(codes.cpu().numpy(), ref.numpy(), tol,
                                  '%s k=%d s=%d step=%g' % (mode, k, s, step),
                                  max_flip_mag=flip)
+
+
+@pytest.mark.parametrize('k,c,s,height,width', [(11, 3, 40, 50, 77),
+                                                (11, 2, 130, 36, 40),
+                                                (16, 3, 33, 40, 48),
+                                                (5, 4, 96, 41, 70),
+                                                (8, 2, 9, 33, 66)])
+def test_split_modes_several_channels(device, plugins, k, c, s, height, width):
+  """Colour images (c > 1) on the matrix cores: the synthesis runs per image
+  channel, the analysis contracts over (channel, dy, dx), the dictionary
+  gradient per channel -- inference (both regimes of the test above, ISTA,
+  early stopping) and both update rules against the oracle at the
+  single-channel tolerances; bitwise reproducible."""
+  conv, steepest, cheapquad = plugins
+  imgs, D, padding = _conv_case(5000 + k + s, k, s, height, width, c=c)
+  Xc, Dc = torch.from_numpy(imgs), torch.from_numpy(D)
+  X, Dd = helpers.to_dev(imgs, device), helpers.to_dev(D, device)
+  eta = sc_oracle.conv_stepsize(Dc)
+  for step, iters, kw in ((float(eta), 6, {}), (0.9 / s, 20, {}),
+                          (0.9 / s, 10, {'variant': 'ista'})):
+    ref = sc_oracle.conv_ista_fista(Xc, Dc, (1, 1), padding, 0.05, iters,
+                                    stepsize=step, **kw)
+    # (with the reference's step the iterates grow geometrically, faster
+    # with more channels: bf16x3's rounding distance from the threshold is
+    # taken relative to the size of the codes)
+    grown = max(1.0, float(ref.abs().max()))
+    for mode, tol, flip in (('f16x3', helpers.REL_TOL_F32,
+                             helpers.NEAR_THRESHOLD),
+                            ('bf16x3', 2e-5, 1e-5 * grown)):
+      codes = conv.run(X, Dd, (1, 1), padding, 0.05, iters, stepsize=step,
+                       precision=mode, **kw)
+      helpers.assert_codes_match(
+          codes.cpu().numpy(), ref.numpy(), tol,
+          '%s k=%d c=%d s=%d step=%g %r' % (mode, k, c, s, step, kw),
+          max_flip_mag=flip)
+      again = conv.run(X, Dd, (1, 1), padding, 0.05, iters, stepsize=step,
+                       precision=mode, **kw)
+      assert torch.equal(codes, again)
+  if s >= 32:
+    auto = conv.run(X, Dd, (1, 1), padding, 0.05, 20, stepsize=0.9 / s)
+    f16 = conv.run(X, Dd, (1, 1), padding, 0.05, 20, stepsize=0.9 / s,
+                   precision='f16x3')
+    assert torch.equal(auto, f16)               # 'auto' takes this route
+  # dictionary updates (gradient per channel on the matrix cores)
+  rs = np.random.RandomState(k * s + c)
+  ch, cw = height + k - 1, width + k - 1
+  codes = (rs.randn(2, s, ch, cw) * (rs.rand(2, s, ch, cw) < 0.2)).astype(
+      np.float32) * 0.05
+  hd = (0.01 + 0.05 * rs.rand(s)).astype(np.float32)
+  C = helpers.to_dev(codes, device)
+  refD = torch.from_numpy(D.copy())
+  sc_oracle.conv_steepest_descent(Xc, refD, torch.from_numpy(codes), (1, 1),
+                                  padding, stepsize=0.005)
+  Dg = helpers.to_dev(D.copy(), device)
+  steepest.run(X, Dg, C, (1, 1), padding, stepsize=0.005)
+  assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
+  refD = torch.from_numpy(D.copy())
+  sc_oracle.conv_cheap_quadratic_descent(
+      Xc, refD, torch.from_numpy(codes), torch.from_numpy(hd), (1, 1), padding,
+      stepsize=0.005)
+  Dg = helpers.to_dev(D.copy(), device)
+  cheapquad.run(X, Dg, C, helpers.to_dev(hd, device), (1, 1), padding,
+                stepsize=0.005)
+  assert helpers.rel_err(Dg.cpu().numpy(), refD.numpy()) < 5e-6
 
 
 @pytest.mark.parametrize('split', ['f16x3', 'bf16x3'])
@@ -291,8 +356,8 @@ def test_split_modes_options_and_reproducibility(device, plugins, split):
 
 
 def test_bf16x3_unsupported_geometry(device, plugins):
-  """Strided or multi-channel geometries have no bf16x3 path: explicit
-  request fails, 'auto' falls back to the direct f32 kernels."""
+  """Strided geometries have no split-precision path: an explicit request
+  fails, 'auto' falls back to the exact-f32 kernels."""
   conv = plugins[0]
   rs = np.random.RandomState(5)
   imgs = (0.5 * rs.randn(1, 2, 40, 40)).astype(np.float32)

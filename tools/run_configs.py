@@ -1,7 +1,7 @@
 """Times the secondary configurations of BASELINE.json (configs[3], configs[4])
 at full size.  Parity of these paths is covered by tests/; this prints speed.
 
-  python3 tools/run_configs.py [subspace] [conv]
+  python3 tools/run_configs.py [subspace] [conv] [conv_geometries]
 """
 import pathlib
 import sys
@@ -74,6 +74,47 @@ def conv(dev):
   print('          conv dictionary update: %.2f ms' % (dt * 1e3))
 
 
+def conv_geometries(dev):
+  """Stride-1 geometries beside configs[4] on the matrix-core routes: the
+  reference's own kernel size (16x16, vtc/tests/ista_fista_2.py:16-24) and
+  colour images -- time per image-iteration and the distance of the split
+  result from the exact-f32 kernels (convergent step, 20 iterations)."""
+  from analysis_transforms.convolutional import ista_fista
+  from dict_update_rules.convolutional import sc_steepest_descent
+  iters, b, img = 20, 8, 256
+  print('%-34s %-8s %10s %14s %12s' % ('geometry (stride 1, 256x256, b=8)',
+                                       'mode', 'ms/img-it', 'TFLOP/s',
+                                       'vs f32'))
+  for k, c, s in ((16, 1, 64), (16, 1, 128), (11, 3, 128), (16, 3, 64),
+                  (8, 3, 96), (5, 1, 128)):
+    pad = k - 1
+    rs = np.random.RandomState(k + c + s)
+    X = np.zeros((b, c, img + 2 * pad, img + 2 * pad), np.float32)
+    X[:, :, pad:pad + img, pad:pad + img] = 0.1 * rs.randn(b, c, img, img)
+    D = rs.randn(s, c, k, k).astype(np.float32)
+    D /= np.sqrt((D ** 2).sum(axis=(1, 2, 3)))[:, None, None, None]
+    X, D = torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev)
+    padding = ((pad, pad), (pad, pad))
+    side = img + pad
+    flop_iter = 4.0 * s * c * k * k * side * side
+    exact = None
+    for prec in ('f32', 'f16x3', 'bf16x3'):
+      dt, codes = timed(lambda: ista_fista.run(
+          X, D, (1, 1), padding, 0.02, iters, stepsize=0.9 / s,
+          precision=prec))
+      if exact is None:
+        exact = codes
+      diff = float(torch.linalg.norm((codes - exact).double()) /
+                   torch.linalg.norm(exact.double()))
+      print('%-34s %-8s %10.3f %14.1f %12.2e' % (
+          '%d kernels %dx%d, %d channel(s)' % (s, k, k, c), prec,
+          dt * 1e3 / (b * iters), flop_iter * b * iters / dt / 1e12, diff))
+    dt, _ = timed(lambda: sc_steepest_descent.run(X, D.clone(), exact, (1, 1),
+                                                  padding, stepsize=0.005))
+    print('%-34s %-8s %10.2f ms per dictionary update' % ('', 'auto',
+                                                          dt * 1e3))
+
+
 if __name__ == '__main__':
   which = sys.argv[1:] or ['subspace', 'conv']
   dev = torch.device('cuda:0')
@@ -81,3 +122,5 @@ if __name__ == '__main__':
     subspace(dev)
   if 'conv' in which:
     conv(dev)
+  if 'conv_geometries' in which:
+    conv_geometries(dev)

@@ -539,8 +539,8 @@ extern "C" int vtc_conv_ista_fista(
   const bool x3 = (precision == VTC_BF16X3 || precision == VTC_F16X3);
   const bool f16 = (precision == VTC_F16X3);
   if (x3 && !cx_plan(g, &xp)) {
-    set_error("vtc_conv_ista_fista: the split modes cover one channel, stride 1 and "
-              "square kernels of 5, 8, 11 or 16 (see "
+    set_error("vtc_conv_ista_fista: the split modes cover stride 1 and square "
+              "kernels of 5, 8, 11 or 16 whose planes fit the LDS (see "
               "vtc_conv_x3_supported)");
     return VTC_ERR_UNSUPPORTED;
   }

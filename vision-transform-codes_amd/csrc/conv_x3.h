@@ -126,33 +126,45 @@ __device__ __forceinline__ void cx_split1(float v, uint16_t& hi, uint16_t& lo) {
 }
 
 // ------------------------------------------------------------------ pack
-// syn image (uint16): [plane][slot][s16 + 8]      D[s][tap(slot)], k = s
-// ana image (uint16): [chunk][plane][dy][2][AC][8]  D[chunk*AC + a][dy][8 h + j]
+// syn image (uint16): [channel][atom chunk][plane][slot][s16 + 8]
+//                                    D[chunk * s16 + a][channel][tap(slot)], k = a
+// ana image (uint16): [chunk][channel][plane][dy][2][AC][8]
+//                                          D[chunk*AC + a][channel][dy][8 h + j]
+// (blockIdx.y = image channel: the dictionary is (s, c, k, k) row-major)
 template <bool F16>
 __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
                                     uint16_t* __restrict__ syn,
                                     uint16_t* __restrict__ ana, int s, int k,
-                                    int s16, int slots, int AC, int chunks,
+                                    int s16, int syn_chunks, int slots, int AC,
+                                    int chunks,
                                     const float* __restrict__ dscale) {
   const float sigma = F16 ? dscale[0] : 1.f;
   const int taps = k * k;
-  const int pitch = s16 + 8;
+  const int pitch = s16 + 8;                       // s16: atoms per syn chunk
   const int64_t syn_plane = (int64_t)slots * pitch;
+  const int64_t syn_all = (int64_t)syn_chunks * syn_plane;
   const int64_t ana_plane = (int64_t)k * AC * 16;
-  const int64_t total = syn_plane + (int64_t)chunks * ana_plane;
+  const int64_t total = syn_all + (int64_t)chunks * ana_plane;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int channel = blockIdx.y, channels = gridDim.y;
+  D += (int64_t)channel * taps;
+  syn += (int64_t)channel * 2 * syn_all;
+  const int64_t kernel_elems = (int64_t)channels * taps;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += stride) {
     float v = 0.f;
     uint16_t *hi, *lo;
-    if (e < syn_plane) {
-      const int slot = (int)(e / pitch), a = (int)(e % pitch);
+    if (e < syn_all) {
+      const int q = (int)(e / syn_plane);
+      const int within = (int)(e % syn_plane);
+      const int slot = within / pitch, a = within % pitch;
       const int t = cx_slot_tap(slot, k);
-      if (a < s && t >= 0) v = D[(int64_t)a * taps + t];
-      hi = syn + e;
-      lo = syn + syn_plane + e;
+      if (a < s16 && q * s16 + a < s && t >= 0)
+        v = D[(int64_t)(q * s16 + a) * kernel_elems + t];
+      hi = syn + (int64_t)q * 2 * syn_plane + within;
+      lo = hi + syn_plane;
     } else {
-      const int64_t f = e - syn_plane;
+      const int64_t f = e - syn_all;
       const int chunk = (int)(f / ana_plane);
       const int rem = (int)(f % ana_plane);
       // [dy][half][atom][8]: the two half-waves of an operand read (taps
@@ -161,8 +173,8 @@ __global__ void conv_x3_pack_kernel(const float* __restrict__ D,
       const int dy = rem / (AC * 16), within = rem % (AC * 16);
       const int a = chunk * AC + (within / 8) % AC,
                 dx = 8 * (within / (AC * 8)) + within % 8;
-      if (a < s && dx < k) v = D[(int64_t)a * taps + dy * k + dx];
-      hi = ana + (int64_t)chunk * 2 * ana_plane + rem;
+      if (a < s && dx < k) v = D[(int64_t)a * kernel_elems + dy * k + dx];
+      hi = ana + ((int64_t)chunk * channels + channel) * 2 * ana_plane + rem;
       lo = hi + ana_plane;
     }
     cx_split1<F16>(v * sigma, *hi, *lo);
@@ -200,7 +212,7 @@ template <int K, bool F16>
 __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     const float* __restrict__ Y, const uint16_t* __restrict__ syn_image,
     const float* __restrict__ X, float* __restrict__ R, ConvGeo g, int s16,
-    int tiles_x, int tiles_y, int rows_per_wave, CxScales sc) {
+    int syn_chunks, int tiles_x, int tiles_y, int rows_per_wave, CxScales sc) {
   using Dm = CxDims<K>;
   constexpr int MT = Dm::MT, NI = Dm::NI, TW = Dm::TW, PW = Dm::PW;
   // tile height: the waves' code rows y0-(K-1) .. y0-(K-1)+8*rows-1 reach the
@@ -225,6 +237,10 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   // F16: Y enters as sigma_Y Y, the kernels as sigma_D D; the reconstruction
   // comes back by 1 / (sigma_Y sigma_D) before the image is subtracted
   if (F16) cx_clear_words(sc.y_zero, sc.images);
+  // blockIdx.y = image channel: its own kernel planes, its own plane of the
+  // images; the code maps are shared
+  const int channel = blockIdx.y;
+  syn_image += (int64_t)channel * syn_chunks * 2 * plane;
   const int64_t strips = g.b * tiles_x;
   const int64_t slot = (int64_t)blockIdx.x >> 3;
   const int64_t strip = (slot / tiles_y) * 8 + (blockIdx.x & 7);
@@ -238,14 +254,7 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     cx_scale_of_bits(sc.y_in ? sc.y_in[img] : 0u, &y_scale, &inv_y);
     unscale = inv_y * sc.dscale[1];
   }
-  {
-    const int n16 = plane / 4;                     // 2 planes * 2 B / 16 B
-    const uint4* src = reinterpret_cast<const uint4*>(syn_image);
-    uint4* dst = reinterpret_cast<uint4*>(lds);
-    for (int i = tid; i < n16; i += 512) dst[i] = src[i];
-    for (int i = tid; i < kCxSynWaves * TH * PW; i += 512) priv[i] = 0.f;
-  }
-  __syncthreads();
+  for (int i = tid; i < kCxSynWaves * TH * PW; i += 512) priv[i] = 0.f;
   const int x0 = tile_x * TW, y0 = tile_y * TH;
   float* mine = priv + wave * TH * PW;
   const int64_t map = (int64_t)g.ch * g.cw;
@@ -258,7 +267,6 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)Yimg, 0, (int)((int64_t)g.s * map * 4), 0x00020000);
   const unsigned map4 = (unsigned)(map * 4);
-  const bool ragged = (g.s != s16);                // last K step has no atom
 
   // The work of a wave is a flat sequence of batches q = ((row, column pass),
   // 2 or 4 K steps of 16 atoms); the operand loads of batch q+1 are in flight while
@@ -282,10 +290,15 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   auto col0_of = [&](int q) {
     return x0 - (K - 1) + 32 * NI * ((q / nbat) % PASSES);
   };
+  // Kernel sets whose planes would leave no room for a sensible tile (128
+  // kernels of 16x16: 139 KB) go through the LDS in `syn_chunks` chunks of s16
+  // atoms; the private tiles accumulate over the chunks.
+  int atom0 = 0;                                   // first atom of the chunk
   auto issue = [&](int q, float (&dst)[NI][kBatch][8]) {
     const int u = row_of(q);
     if (u < 0 || u >= g.ch) return;                // whole wave
     const int bt = q % nbat;
+    const bool ragged = atom0 + s16 > g.s;         // some K step lacks atoms
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int v = col0_of(q) + 32 * ni + l31;
@@ -297,14 +310,15 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
       for (int kk = 0; kk < kBatch; ++kk) {
         const int ks = bt * kBatch + kk;
         if (ks >= nks) break;
-        const bool guard = ragged && ks + 1 == nks;
+        const bool guard = ragged && atom0 + ks * 16 + 16 > g.s;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           unsigned vo = voff;
-          if (guard && ks * 16 + 8 * half + j >= g.s) vo = 0x80000000u;
+          if (guard && atom0 + ks * 16 + 8 * half + j >= g.s)
+            vo = 0x80000000u;
           dst[ni][kk][j] = __builtin_bit_cast(
               float, __builtin_amdgcn_raw_buffer_load_b32(
-                         yrs, vo, (unsigned)(ks * 16 + j) * map4, 0));
+                         yrs, vo, (unsigned)(atom0 + ks * 16 + j) * map4, 0));
         }
       }
     }
@@ -405,12 +419,24 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
   };
 
   float buf0[NI][kBatch][8], buf1[NI][kBatch][8];
-  issue(0, buf0);
-  for (int q = 0; q < total; q += 2) {
-    if (q + 1 < total) issue(q + 1, buf1);
-    compute(q, buf0);
-    if (q + 2 < total) issue(q + 2, buf0);
-    if (q + 1 < total) compute(q + 1, buf1);
+  for (int chunk = 0; chunk < syn_chunks; ++chunk) {
+    atom0 = chunk * s16;
+    if (chunk != 0) __syncthreads();               // planes of the last chunk
+    {
+      const int n16 = plane / 4;                   // 2 planes * 2 B / 16 B
+      const uint4* src = reinterpret_cast<const uint4*>(syn_image) +
+                         (int64_t)chunk * n16;
+      uint4* dst = reinterpret_cast<uint4*>(lds);
+      for (int i = tid; i < n16; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    issue(0, buf0);
+    for (int q = 0; q < total; q += 2) {
+      if (q + 1 < total) issue(q + 1, buf1);
+      compute(q, buf0);
+      if (q + 2 < total) issue(q + 2, buf0);
+      if (q + 1 < total) compute(q + 1, buf1);
+    }
   }
   __syncthreads();
   float r_max = 0.f;
@@ -423,7 +449,7 @@ __global__ __launch_bounds__(512) void conv_synth_x3_kernel(
     for (int w = 1; w < kCxSynWaves; ++w)
       sum = add_rn(sum, priv[w * TH * PW + py * PW + px]);
     if (F16) sum *= unscale;
-    const int64_t i = (img * g.H + y) * (int64_t)g.W + x;
+    const int64_t i = ((img * g.c + channel) * g.H + y) * (int64_t)g.W + x;
     const float rv = mul_rn(mask_at(g, y, x), sub_rn(sum, X[i]));
     R[i] = rv;
     r_max = fmaxf(r_max, fabsf(rv));
@@ -454,10 +480,12 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int k = g.kh;
   const int plane = k * AC * 16;                   // elements
   const int rows = ana_rows + k - 1;
+  const int win = rows * kCxAnaPitch;              // elements per window plane
+  // per image channel: kernel planes [hi | lo], then window planes [hi | lo]
   uint16_t* Dh = reinterpret_cast<uint16_t*>(lds);
   uint16_t* Dl = Dh + plane;
-  uint16_t* Rh = Dl + plane;
-  uint16_t* Rl = Rh + rows * kCxAnaPitch;
+  uint16_t* Rh = Dh + 2 * plane * g.c;
+  uint16_t* Rl = Rh + win;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -487,16 +515,20 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int u0 = tile_u * ana_rows, v0 = tile_v * kCxStrip;
   {
     const uint4* src = reinterpret_cast<const uint4*>(
-        ana_image + (int64_t)chunk * 2 * plane);
+        ana_image + (int64_t)chunk * g.c * 2 * plane);
     uint4* dst = reinterpret_cast<uint4*>(lds);
-    const int n16 = plane / 4;
+    const int n16 = g.c * (plane / 4);
     for (int i = tid; i < n16; i += 256) dst[i] = src[i];
-    const float* Rimg = R + img * g.H * (int64_t)g.W;
-    for (int e = tid; e < rows * kCxAnaPitch; e += 256) {
-      const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
-      const int y = u0 + ry, x = v0 + rx;
-      const float v = (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
-      cx_split1<F16>(F16 ? v * r_scale : v, Rh[e], Rl[e]);
+    for (int channel = 0; channel < g.c; ++channel) {
+      const float* Rimg = R + (img * g.c + channel) * g.H * (int64_t)g.W;
+      uint16_t* wh = Rh + channel * 2 * win;
+      for (int e = tid; e < win; e += 256) {
+        const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
+        const int y = u0 + ry, x = v0 + rx;
+        const float v =
+            (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
+        cx_split1<F16>(F16 ? v * r_scale : v, wh[e], wh[win + e]);
+      }
     }
   }
   __syncthreads();
@@ -590,11 +622,15 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ma][ni][r] = 0.f;
-    for (int dy = 0; dy < k; ++dy) {
+    // K index = (image channel, dy, 16 dx)
+    for (int cdy = 0; cdy < g.c * k; ++cdy) {
+      const int channel = cdy / k, dy = cdy - channel * k;
+      const int wbase = channel * 2 * win, dbase = channel * 2 * plane;
       uint4 bh[2], bl[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int off = (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
+        const int off =
+            wbase + (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
         const CxUnaligned16 h =
             *reinterpret_cast<const CxUnaligned16*>(Rh + off);
         const CxUnaligned16 l =
@@ -604,7 +640,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       }
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma) {
-        const int off = ((dy * 2 + half) * AC + 32 * ma + l31) * 8;
+        const int off = dbase + ((dy * 2 + half) * AC + 32 * ma + l31) * 8;
         const uint4 ah = *reinterpret_cast<const uint4*>(Dh + off);
         const uint4 al = *reinterpret_cast<const uint4*>(Dl + off);
 #pragma unroll
@@ -1427,6 +1463,7 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int atom0 = (blockIdx.y * 4 + wave) * 32;  // this wave's atom tile
+  const int channel = blockIdx.z;                  // image channel
   const int atom = atom0 + l31;
   const bool atom_ok = atom < g.s;
   const int64_t map = (int64_t)g.ch * g.cw;
@@ -1446,7 +1483,7 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
     const int u0 = tile_u * kCxGradRows, v0 = tile_v * kCxStrip;
     __syncthreads();                               // window of the last item
     {
-      const float* Rimg = R + img * g.H * (int64_t)g.W;
+      const float* Rimg = R + (img * g.c + channel) * g.H * (int64_t)g.W;
       for (int e = tid; e < PLANE; e += 256) {
         const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
         const int y = u0 + ry, x = v0 + rx;
@@ -1509,8 +1546,8 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
       }
     }
   }
-  // this block's partial sums: slab[blockIdx.x][atom][tap]
-  float* slab = slabs + (int64_t)blockIdx.x * g.s * (K * K);
+  // this block's partial sums: slab[blockIdx.x][atom][channel][tap]
+  float* slab = slabs + ((int64_t)blockIdx.x * g.s * g.c + channel) * (K * K);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int dy = 2 * nt + dyi;
@@ -1518,14 +1555,15 @@ __global__ __launch_bounds__(256) void conv_grad_x3_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int a_out = atom0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (a_out < g.s) slab[(int64_t)a_out * (K * K) + dy * K + dx] = acc[nt][r];
+      if (a_out < g.s)
+        slab[(int64_t)a_out * g.c * (K * K) + dy * K + dx] = acc[nt][r];
     }
   }
 }
 
 // ------------------------------------------------------------------ host
 struct CxPlan {
-  int k, s16, slots, AC, chunks;
+  int k, s16, syn_chunks, slots, AC, chunks;
   int syn_rows;      // code rows per wave of the synthesis kernel
   int ana_rows;      // code rows per block of the analysis kernel
   size_t syn_image_bytes, ana_image_bytes;
@@ -1582,15 +1620,31 @@ template <int K>
 static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   using Dm = CxDims<K>;
   p->k = K;
-  p->s16 = (g.s + 15) / 16 * 16;
+  // atoms per LDS-resident chunk of the synthesis planes: everything when the
+  // planes stay under 100 KB (every 11x11 set up to 128 kernels), else the
+  // fewest equal chunks that do
+  {
+    const int all16 = (g.s + 15) / 16 * 16;
+    int parts = 1, per = all16;
+    while ((size_t)2 * Dm::SLOTS * (per + 8) * 2 > 100 * 1024 && per > 16) {
+      ++parts;
+      per = ((all16 / 16 + parts - 1) / parts) * 16;
+    }
+    p->s16 = per;
+    p->syn_chunks = (all16 + per - 1) / per;
+  }
   p->slots = Dm::SLOTS;
-  p->AC = g.s > 32 ? 64 : 32;
+  // atoms per analysis block: 64, or 32 when the kernel planes of all image
+  // channels would not leave room for the windows (3 channels of 11x11)
+  p->AC = (g.s > 32 && (size_t)g.c * 2 * K * 64 * 16 * 2 <= 100 * 1024) ? 64
+                                                                         : 32;
   p->chunks = (g.s + p->AC - 1) / p->AC;
-  p->syn_image_bytes = (size_t)2 * Dm::SLOTS * (p->s16 + 8) * 2;
-  p->ana_image_bytes = (size_t)p->chunks * 2 * K * p->AC * 16 * 2;
-  p->syn_rows = cx_pick_rows(g, K, Dm::TW, Dm::PW, p->syn_image_bytes);
+  const size_t syn_channel_bytes = (size_t)2 * Dm::SLOTS * (p->s16 + 8) * 2;
+  p->syn_image_bytes = (size_t)g.c * p->syn_chunks * syn_channel_bytes;
+  p->ana_image_bytes = (size_t)p->chunks * g.c * 2 * K * p->AC * 16 * 2;
+  p->syn_rows = cx_pick_rows(g, K, Dm::TW, Dm::PW, syn_channel_bytes);
   p->th = kCxSynWaves * p->syn_rows - (K - 1);
-  p->syn_lds = p->syn_image_bytes +
+  p->syn_lds = syn_channel_bytes +
                (size_t)kCxSynWaves * p->th * Dm::PW * sizeof(float);
   // Code rows per analysis block.  Two blocks per CU are resident; with few
   // rounds of blocks the shorter tile fills them better, with many the taller
@@ -1601,13 +1655,13 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
                             ceil_div(g.ch, kCxAnaMaxRows) * p->chunks * g.b;
     p->ana_rows = blocks8 < (int64_t)16 * cx_compute_units() ? 4 : 8;
   }
-  p->ana_lds = (size_t)2 * K * p->AC * 16 * 2 +
-               (size_t)2 * (p->ana_rows + K - 1) * kCxAnaPitch * 2;
+  p->ana_lds = g.c * ((size_t)2 * K * p->AC * 16 * 2 +
+                      (size_t)2 * (p->ana_rows + K - 1) * kCxAnaPitch * 2);
   p->tw = Dm::TW;
   using F = CxFused<K>;
   p->synp_image_bytes = p->partial_bytes = p->fused_lds = 0;
   p->padded_bytes = 0;
-  if (p->AC == 64 && K <= 11 && F::lds <= 160 * 1024) {
+  if (g.c == 1 && p->AC == 64 && K <= 11 && F::lds <= 160 * 1024) {
     p->fused_lds = F::lds;
     p->synp_image_bytes = (size_t)p->chunks * F::syn_bytes;
     p->partial_bytes = (size_t)g.b * ceil_div(g.ch, F::ROWS) * p->chunks *
@@ -1623,10 +1677,14 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
   }
 }
 
-// Geometries this path covers: one channel, stride 1, square kernels of the
-// sizes instantiated below, and operand planes that fit the 160 KiB LDS.
+// Geometries this path covers: stride 1, square kernels of the sizes
+// instantiated below, and operand planes that fit the 160 KiB LDS (up to 4
+// image channels of 11x11 or 16x16 kernels).  Several channels: the synthesis
+// runs per channel (grid.y), the analysis takes (channel, dy, 16 dx) as its K
+// index; the fused iteration kernel is single-channel.
 static bool cx_plan(const ConvGeo& g, CxPlan* p) {
-  if (g.c != 1 || g.sv != 1 || g.sh != 1 || g.kh != g.kw) return false;
+  if (g.c < 1 || g.c > 8 || g.sv != 1 || g.sh != 1 || g.kh != g.kw)
+    return false;
   switch (g.kh) {
     case 5: cx_fill_plan<5>(g, p); break;
     case 8: cx_fill_plan<8>(g, p); break;
@@ -1635,7 +1693,8 @@ static bool cx_plan(const ConvGeo& g, CxPlan* p) {
     default: return false;
   }
   // 32-bit byte offsets within one image's code maps (buffer addressing)
-  const int64_t code_bytes = (int64_t)p->s16 * g.ch * g.cw * 4;
+  const int64_t code_bytes =
+      (int64_t)p->s16 * p->syn_chunks * g.ch * g.cw * 4;
   return p->syn_rows > 0 && p->syn_lds <= 150 * 1024 &&
          p->ana_lds <= 150 * 1024 &&
          g.b <= 65535 && code_bytes < (int64_t)0x7fffffff;
@@ -1757,13 +1816,13 @@ static int cx_pack(const float* D, const ConvGeo& g, const CxPlan& p,
                    uint16_t* syn, uint16_t* ana, const float* dscale,
                    hipStream_t st) {
   if (dscale)
-    hipLaunchKernelGGL(conv_x3_pack_kernel<true>, dim3(256), dim3(256), 0, st,
-                       D, syn, ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks,
-                       dscale);
+    hipLaunchKernelGGL(conv_x3_pack_kernel<true>, dim3(256, (unsigned)g.c),
+                       dim3(256), 0, st, D, syn, ana, g.s, p.k, p.s16,
+                       p.syn_chunks, p.slots, p.AC, p.chunks, dscale);
   else
-    hipLaunchKernelGGL(conv_x3_pack_kernel<false>, dim3(256), dim3(256), 0, st,
-                       D, syn, ana, g.s, p.k, p.s16, p.slots, p.AC, p.chunks,
-                       dscale);
+    hipLaunchKernelGGL(conv_x3_pack_kernel<false>, dim3(256, (unsigned)g.c),
+                       dim3(256), 0, st, D, syn, ana, g.s, p.k, p.s16,
+                       p.syn_chunks, p.slots, p.AC, p.chunks, dscale);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
@@ -1787,8 +1846,9 @@ static int cx_launch_synth_k(const float* Y, const uint16_t* syn,
     set_error("conv bf16x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((conv_synth_x3_kernel<K, F16>), dim3((unsigned)blocks),
-                     dim3(512), p.syn_lds, st, Y, syn, X, R, g, p.s16,
+  hipLaunchKernelGGL((conv_synth_x3_kernel<K, F16>),
+                     dim3((unsigned)blocks, (unsigned)g.c), dim3(512),
+                     p.syn_lds, st, Y, syn, X, R, g, p.s16, p.syn_chunks,
                      tiles_x, tiles_y, p.syn_rows, sc);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
@@ -1871,7 +1931,7 @@ static int cx_launch_grad_k(const float* R, const float* C, float* slabs,
   const int64_t items = (int64_t)tiles_v * tiles_u * g.b;
   hipLaunchKernelGGL(conv_grad_x3_kernel<K>,
                      dim3((unsigned)cx_grad_blocks(g),
-                          (unsigned)ceil_div(g.s, 128)),
+                          (unsigned)ceil_div(g.s, 128), (unsigned)g.c),
                      dim3(256), 0, st, R, C, slabs, g, tiles_v, tiles_u, items);
   VTC_LAUNCH_CHECK();
   return VTC_OK;

@@ -38,8 +38,8 @@ def descend(images_padded, dictionary, codes, kernel_stride, padding_dims,
   scratch = torch.empty_like(dictionary)
   total_batch = parallel.global_batch(geom.b, device)
   # precision policy of the process (vtc_hip.set_default_precision): 'auto'
-  # takes the matrix-core route where the inference plugin does (one channel,
-  # stride 1, square kernels 5/8/11/16, at least 32 kernels).  The gradient is
+  # takes the matrix-core route where the inference plugin does (stride 1,
+  # square kernels 5/8/11/16, at least 32 kernels).  The gradient is
   # a single product -- nothing iterates on its rounding -- and runs on the
   # bf16 split whichever split mode is named (5e-6 on the updated kernels)
   name = vtc_hip.get_default_precision()
