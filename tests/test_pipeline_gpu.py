@@ -1,7 +1,7 @@
 """The production pipeline end to end at the headline shape (16x16 patches,
 1024 atoms) against a trajectory recorded from the reference's own
 train_dictionary (tests/golden/trainer_c2.npz, oracle/make_golden.py
-make_trainer_c2): Gram -> Lanczos eta -> fused bf16x3 FISTA -> code energy ->
+make_trainer_c2): Gram -> Lanczos eta -> fused f16x3 FISTA -> code energy ->
 Hessian EMA -> dictionary gradient -> apply, with the DEFAULT precision policy
 and NO injected stepsize."""
 import numpy as np
