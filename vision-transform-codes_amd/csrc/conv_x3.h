@@ -1384,11 +1384,10 @@ __global__ void conv_from_fragments_kernel(const float* __restrict__ src,
 // grid = (blocks per image, images); r_max_out (may be null): the per-image
 // words that receive max |R| (CxScales)
 template <int K>
-__global__ void conv_partial_reduce_kernel(const float* __restrict__ partial,
-                                           const float* __restrict__ X,
-                                           float* __restrict__ R, ConvGeo g,
-                                           int tiles_v, int tiles_u,
-                                           int chunks, unsigned* r_max_out) {
+__global__ __launch_bounds__(1024) void conv_partial_reduce_kernel(
+    const float* __restrict__ partial, const float* __restrict__ X,
+    float* __restrict__ R, ConvGeo g, int tiles_v, int tiles_u, int chunks,
+    unsigned* r_max_out) {
   using F = CxFused<K>;
   __shared__ unsigned red[16];
   float r_max = 0.f;
@@ -1771,10 +1770,15 @@ static int cx_launch_fused_k(const float* R, const uint16_t* ana,
               (double)host[q] / (double)host[9]);
   }
   if (do_synth) {
-    int64_t rblocks = ceil_div((int64_t)g.H * g.W, 256);
+    // Blocks of 1024 pixels: all blocks of an image finish together and each
+    // adds one atomic to the image's maximum word (f16 mode) -- with 256-pixel
+    // blocks the ~300 read-modify-writes per word queued for 30 us behind a
+    // 13 us kernel (a look at the word first does not help: every block
+    // starts while it is still zero).
+    int64_t rblocks = ceil_div((int64_t)g.H * g.W, 1024);
     if (rblocks > 4096) rblocks = 4096;
     hipLaunchKernelGGL(conv_partial_reduce_kernel<K>,
-                       dim3((unsigned)rblocks, (unsigned)g.b), dim3(256), 0,
+                       dim3((unsigned)rblocks, (unsigned)g.b), dim3(1024), 0,
                        st, partial, X, R_next, g, tiles_v, tiles_u, p.chunks,
                        F16 ? sc.r_out : nullptr);
     VTC_LAUNCH_CHECK();
