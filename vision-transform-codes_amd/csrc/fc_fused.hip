@@ -647,6 +647,13 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
 
 }  // namespace vtc
 
+// Experiments kept out of the library (profiles/r03_fused_onepacking.txt).
+// Eight waves per workgroup (two per SIMD, 16-atom step-1 tiles): build with
+// -DVTC_EXPERIMENT_EIGHT_WAVES, run with VTC_FUSED_8W=1.
+#ifdef VTC_EXPERIMENT_EIGHT_WAVES
+#include "../../tools/micro/fc_fused8.h"
+#endif
+
 // Experiment kept out of the library (profiles/r03_fused_onepacking.txt): a
 // variant that keeps part of each phase's dictionary tile in LDS and reads it
 // back transposed instead of streaming packT.  Build with
@@ -800,9 +807,86 @@ static int dispatch_mode1p(const FusedParams& P, int threshold, int nt,
 
 #endif
 
+#ifdef VTC_EXPERIMENT_EIGHT_WAVES
+// Eight-wave form (tools/micro/fc_fused8.h), three-product modes.
+static bool fused_eight_waves() {
+  static const bool on = [] {
+    const char* v = getenv("VTC_FUSED_8W");
+    return v != nullptr && atoi(v) != 0;
+  }();
+  return on;
+}
+
+template <int NPH, int MODE, bool F16>
+static int launch_fused8(const FusedParams& P, hipStream_t st) {
+  using L = Fused8Lds<NPH>;
+  auto kernel = fused8_kernel<NPH, MODE, F16>;
+  static unsigned long long configured = 0;
+  if (first_use_on_this_device(&configured)) {
+    VTC_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+  }
+  const unsigned grid = (unsigned)ceil_div(P.b, kFP);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+template <int NPH, bool F16>
+static int launch_stamped8(FusedParams P, hipStream_t st) {
+  using L = Fused8Lds<NPH>;
+  auto kernel = fused8_kernel<NPH, VTC_SOFT, F16, true>;
+  unsigned long long* dev = nullptr;
+  VTC_HIP_CHECK(hipMalloc(&dev, 8 * sizeof(unsigned long long)));
+  VTC_HIP_CHECK(hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), st));
+  VTC_HIP_CHECK(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(kernel),
+      hipFuncAttributeMaxDynamicSharedMemorySize, L::total));
+  P.stamps = dev;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)ceil_div(P.b, kFP)), dim3(512),
+                     L::total, st, P);
+  VTC_LAUNCH_CHECK();
+  unsigned long long host[8];
+  VTC_HIP_CHECK(hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost,
+                               st));
+  VTC_HIP_CHECK(hipStreamSynchronize(st));
+  VTC_HIP_CHECK(hipFree(dev));
+  const char* names[5] = {"step1+epi", "epi-alone", "barrier", "step3",
+                          "exchange"};
+  double total = 0;
+  for (int k = 0; k < 5; ++k) total += (double)host[k];
+  const double per = (double)host[7] * P.num_iters * NPH;
+  for (int k = 0; k < 5; ++k)
+    fprintf(stderr, "[vtc stamps 8w] %-9s %5.1f%%  %8.0f cycles/phase/wave\n",
+            names[k], 100.0 * host[k] / total, host[k] / per);
+  fprintf(stderr, "[vtc stamps 8w] barrier wait of waves 0-3: %.0f, of waves "
+          "4-7: %.0f cycles/phase/wave\n", 2.0 * host[5] / per,
+          2.0 * host[6] / per);
+  return VTC_OK;
+}
+
+template <int NPH, bool F16>
+static int dispatch_mode8(const FusedParams& P, int threshold, hipStream_t st) {
+  static const bool stamps = getenv("VTC_FUSED_STAMPS") != nullptr;
+  if (stamps && threshold == VTC_SOFT && NPH == 8)
+    return launch_stamped8<NPH, F16>(P, st);
+  switch (threshold) {
+    case VTC_SOFT: return launch_fused8<NPH, VTC_SOFT, F16>(P, st);
+    case VTC_SOFT_NONNEG: return launch_fused8<NPH, VTC_SOFT_NONNEG, F16>(P, st);
+    case VTC_HARD: return launch_fused8<NPH, VTC_HARD, F16>(P, st);
+    default: return launch_fused8<NPH, VTC_HARD_NONNEG, F16>(P, st);
+  }
+}
+#endif
+
 template <int NPH, int NP, bool F16>
 static int dispatch_mode(const FusedParams& P, int threshold, hipStream_t st) {
   static const bool stamps = getenv("VTC_FUSED_STAMPS") != nullptr;
+#ifdef VTC_EXPERIMENT_EIGHT_WAVES
+  if (NP == 2 && fused_eight_waves())
+    return dispatch_mode8<NPH, F16>(P, threshold, st);
+#endif
 #ifdef VTC_EXPERIMENT_ONE_PACKING
   static const int one_packing =
       getenv("VTC_FUSED_1P") ? atoi(getenv("VTC_FUSED_1P")) : 0;
@@ -909,6 +993,18 @@ int run_fused(const float* images, const float* dictionary,
                        st, dictionary, (int)s, packs[0], packs[1], packs[2],
                        packs[3], dscale);
   VTC_LAUNCH_CHECK();
+#ifdef VTC_EXPERIMENT_EIGHT_WAVES
+  if (parts == 2 && fused_eight_waves()) {
+    // the eight-wave kernel reads its step-1 operand as 16-atom tiles
+    if (f16)
+      hipLaunchKernelGGL(pack_dictionary8_kernel<true>, dim3(256), dim3(256), 0,
+                         st, dictionary, (int)s, packs[0], packs[2], dscale);
+    else
+      hipLaunchKernelGGL(pack_dictionary8_kernel<false>, dim3(256), dim3(256),
+                         0, st, dictionary, (int)s, packs[0], packs[2], dscale);
+    VTC_LAUNCH_CHECK();
+  }
+#endif
   P.images = images;
   P.init = initial_codes;
   P.codes = codes;
