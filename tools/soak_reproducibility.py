@@ -67,17 +67,21 @@ for m, G, prec in ((4, 75, 'bf16x3'), (4, 75, 'f16x3'), (3, 100, 'f32'),
     print('subspace %s m=%d: skipped (%s)' % (prec, m, type(e).__name__))
 # convolution: f32 unit-stride kernels, bf16x3 two-kernel route (16x16
 # kernels), fused route (11x11), strided patch route
-for k, s, stride, prec, label in ((11, 24, 1, 'f32', 'f32 unit-stride'),
-                                  (16, 40, 1, 'bf16x3', 'bf16x3 two kernels'),
-                                  (11, 128, 1, 'bf16x3', 'bf16x3 fused'),
-                                  (16, 40, 1, 'f16x3', 'f16x3 two kernels'),
-                                  (11, 128, 1, 'f16x3', 'f16x3 fused'),
-                                  (16, 32, 8, 'f32', 'f32 patch route')):
+# (colour images and chunked synthesis planes: the two-kernel route of round 3)
+for k, s, stride, prec, label, c in (
+    (11, 24, 1, 'f32', 'f32 unit-stride', 1),
+    (16, 40, 1, 'bf16x3', 'bf16x3 two kernels', 1),
+    (11, 128, 1, 'bf16x3', 'bf16x3 fused', 1),
+    (16, 40, 1, 'f16x3', 'f16x3 two kernels', 1),
+    (11, 128, 1, 'f16x3', 'f16x3 fused', 1),
+    (11, 96, 1, 'f16x3', 'f16x3 two kernels, 3 channels', 3),
+    (16, 112, 1, 'f16x3', 'f16x3 two kernels, chunked planes', 1),
+    (16, 32, 8, 'f32', 'f32 patch route', 1)):
   img, b = 200, 4
   pad = k - 1 if stride == 1 else 8
-  X = np.zeros((b, 1, img + 2 * pad, img + 2 * pad), np.float32)
-  X[:, :, pad:pad + img, pad:pad + img] = 0.1 * rs.randn(b, 1, img, img)
-  D = rs.randn(s, 1, k, k).astype(np.float32)
+  X = np.zeros((b, c, img + 2 * pad, img + 2 * pad), np.float32)
+  X[:, :, pad:pad + img, pad:pad + img] = 0.1 * rs.randn(b, c, img, img)
+  D = rs.randn(s, c, k, k).astype(np.float32)
   D /= np.sqrt((D ** 2).sum(axis=(1, 2, 3)))[:, None, None, None]
   Xd, Dd = torch.from_numpy(X).to(dev), torch.from_numpy(D).to(dev)
   padding = ((pad, pad), (pad, pad))
