@@ -25,6 +25,7 @@ echo "== secondary configs"
 timeout -k 10 300 python3 tools/run_configs.py > $out/secondary_configs.txt 2>&1; grep -v amdgpu $out/secondary_configs.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/cfg_stats -o c -- python3 tools/run_configs.py > /dev/null 2>&1
 cp $out/cfg_stats/c_kernel_stats.csv $out/secondary_kernel_stats.csv 2>/dev/null
+timeout -k 10 300 python3 tools/run_configs.py conv_geometries 2>&1 | grep -v amdgpu > $out/conv_geometries.txt; cat $out/conv_geometries.txt
 echo "== PMC passes, streamed kernel (subspace configs[3], 50 iterations)"
 run_pmc st1 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 tools/run_subspace_once.py
 run_pmc st2 FETCH_SIZE -- python3 tools/run_subspace_once.py
@@ -41,6 +42,8 @@ VTC_CONV_STAMPS=1 timeout -k 10 100 python3 tools/run_configs.py conv 2>&1 | gre
 timeout -k 10 60 tools/micro/lds_unaligned > $out/lds_unaligned.txt 2>&1; cat $out/lds_unaligned.txt
 [ -x tools/peaks/peaks ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/peaks/peaks.hip -o tools/peaks/peaks 2>/dev/null
 timeout -k 10 120 tools/peaks/peaks > $out/peaks.txt 2>&1; grep -i "HBM\|MFMA\|stream" $out/peaks.txt
+[ -x tools/micro/stream_mfma ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/micro/stream_mfma.hip -o tools/micro/stream_mfma 2>/dev/null
+timeout -k 10 60 tools/micro/stream_mfma > $out/stream_mfma.txt 2>&1; cat $out/stream_mfma.txt
 timeout -k 10 300 python3 tools/precision_conv_report.py 2>&1 | grep -v amdgpu > $out/precision_conv.txt; tail -8 $out/precision_conv.txt
 timeout -k 10 300 python3 tools/precision_report.py 2>&1 | grep -v amdgpu > $out/precision_fc.txt; tail -12 $out/precision_fc.txt
 echo "== fully-connected shapes outside the headline kernel, reproducibility soak"
