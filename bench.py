@@ -275,7 +275,9 @@ def main():
                   'by the L2->VGPR streaming rate of a CU (dictionary '
                   'fragments: 57.9 of a measured 58 B/clk/CU; removing the '
                   'whole epilogue arithmetic buys 4.4 %: '
-                  'profiles/r02_fused_ceiling.txt)'},
+                  'profiles/r02_fused_ceiling.txt); one fragment packing per '
+                  'iteration and an eight-wave form were built and measured '
+                  'slower / equal (profiles/r03_fused_onepacking.txt)'},
   }
   if world == 1 and precision != 'bf16' and ista_fista.fused_available():
     # the other fused modes on the same inputs, reported beside the headline:
