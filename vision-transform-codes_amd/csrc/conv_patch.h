@@ -121,22 +121,37 @@ struct EpiPatchProx {
   int64_t s, map;
   ProxParams pp;
   double local;
-  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float v,
-                                             int) {
+  // two-phase protocol of gemm_f32.h: Y and the previous codes are read
+  // before the K loop, nothing waits on memory afterwards
+  static constexpr bool kElemFetch = true;
+  struct Fetched {
+    float yv, cv;
+  };
+  __device__ __forceinline__ int64_t index_of(int64_t row, int64_t col) const {
     // (positions fit 32 bits -- patch_geometry limits the route to small
     // maps -- and a 64-bit division per output element cost more than the
     // proximal step itself)
     const unsigned img32 = (unsigned)col / (unsigned)map;
     const int64_t img = img32, pq = col - img * map;
-    const int64_t idx = (img * s + row) * map + pq;
-    const float yv = Y[idx];
-    const float c = shrink(sub_rn(yv, mul_rn(pp.eta, v)), pp.cutoff, pp.mode);
+    return (img * s + row) * map + pq;
+  }
+  __device__ __forceinline__ Fetched fetch(int64_t row, int64_t col) const {
+    const int64_t idx = index_of(row, col);
+    Fetched f;
+    f.yv = Y[idx];
+    f.cv = pp.fista ? C[idx] : 0.f;
+    return f;
+  }
+  __device__ __forceinline__ void apply(int64_t row, int64_t col, float v, int,
+                                        const Fetched& f) {
+    const int64_t idx = index_of(row, col);
+    const float c = shrink(sub_rn(f.yv, mul_rn(pp.eta, v)), pp.cutoff, pp.mode);
     float d;
     if (pp.fista) {
-      d = sub_rn(c, C[idx]);
+      d = sub_rn(c, f.cv);
       pp.y_out[idx] = add_rn(c, mul_rn(pp.beta, d));
     } else {
-      d = sub_rn(c, yv);
+      d = sub_rn(c, f.yv);
     }
     pp.c_out[idx] = c;
     if (pp.delta_sum) local += (double)(fabsf(d) / pp.eta);

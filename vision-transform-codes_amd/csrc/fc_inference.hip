@@ -43,17 +43,29 @@ struct EpiProx {
     }
   }
 
-  __device__ __forceinline__ void operator()(int64_t row, int64_t col, float g,
-                                             int) {
+  // two-phase protocol of gemm_f32.h (the targets Yo / Co are other buffers):
+  // Y and the previous codes are read before the K loop
+  static constexpr bool kElemFetch = true;
+  struct Fetched {
+    float y, c;
+  };
+  __device__ __forceinline__ Fetched fetch(int64_t row, int64_t col) const {
     const int64_t i = row * ld + col;
-    const float y = Y[i];
-    const float c = shrink(sub_rn(y, mul_rn(eta, g)), cutoff, mode);
+    Fetched f;
+    f.y = Y[i];
+    f.c = fista ? C[i] : 0.f;
+    return f;
+  }
+  __device__ __forceinline__ void apply(int64_t row, int64_t col, float g, int,
+                                        const Fetched& f) {
+    const int64_t i = row * ld + col;
+    const float c = shrink(sub_rn(f.y, mul_rn(eta, g)), cutoff, mode);
     float d;
     if (fista) {
-      d = sub_rn(c, C[i]);
+      d = sub_rn(c, f.c);
       Yo[i] = add_rn(c, mul_rn(beta, d));
     } else {
-      d = sub_rn(c, y);
+      d = sub_rn(c, f.y);
     }
     Co[i] = c;
     if (delta_sum) local += (double)(fabsf(d) / eta);

@@ -59,6 +59,24 @@ struct epi_prefetch_floats<E, true> {
   static constexpr int value = E::kPrefetch;
 };
 
+// An element-wise epilogue that reads per-element state (the proximal step of
+// the strided convolution: Y and the previous codes) may declare
+//   struct Fetched; static constexpr bool kElemFetch = true;
+//   Fetched fetch(row, col) const;      apply(row, col, acc, z, fetched)
+// The kernels then issue every fetch of a thread BEFORE the K loop and apply
+// after it: written as load-compute-store per element, each load waits for the
+// stores before it (they may alias), 64 memory round trips per thread -- 50 of
+// the 71 us of the analysis contraction at the reference's example geometry.
+template <class E, class = void>
+struct epi_elem_fetch : std::false_type {};
+template <class E>
+struct epi_elem_fetch<E, std::void_t<decltype(E::kElemFetch)>>
+    : std::true_type {};
+template <class E, bool = epi_elem_fetch<E>::value>
+struct epi_fetched { struct type {}; };
+template <class E>
+struct epi_fetched<E, true> { typedef typename E::Fetched type; };
+
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 x3_bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int x3_u32x4 __attribute__((ext_vector_type(4)));
@@ -178,6 +196,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
   if constexpr (kPipe)
     epi.load(ctx, wm * 64, n0 + wn * 64, lane, g.N, pre0);
 
+  constexpr bool kFetch = epi_elem_fetch<Epi>::value;
+  typename epi_fetched<Epi>::type fetched[kFetch ? 64 : 1];
+  if constexpr (kFetch) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t col = n0 + (wave & 1) * 64 + (t & 1) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + (wave >> 1) * 64 + (t >> 1) * 32 + (r & 3) +
+                            8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M && col < g.N)
+          fetched[16 * t + r] =
+              epi.fetch(row + (int64_t)blockIdx.z * g.M, col);
+      }
+    }
+  }
+
   float4 ra[2], rb[2];
   if (nk > 0) {
     stage_load<A_KC>(g.A, g.lda, m0, g.M, k_begin, k_end, g.a_vec, tid, ra);
@@ -244,12 +279,30 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_f32_kernel(GemmArgs g,
       for (int r = 0; r < 16; ++r) {
         const int64_t row =
             m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < g.M && col < g.N)
-          epi(row + row_shift, col, acc[mi][ni][r], z);
+        if (row < g.M && col < g.N) {
+          if constexpr (kFetch)
+            epi.apply(row + row_shift, col, acc[mi][ni][r], z,
+                      fetched[16 * (2 * mi + ni) + r]);
+          else
+            epi(row + row_shift, col, acc[mi][ni][r], z);
+        }
       }
     }
   }
   epi.block_end();
+}
+
+static int gemm_compute_units() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess &&
+           hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount,
+                                 dev) == hipSuccess && n > 0)
+              ? n
+              : 256;
+  }
+  return cus;
 }
 
 static inline int gemm_vec_ok(const float* p, int64_t ld) {
@@ -274,6 +327,10 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   const int64_t m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
   const int64_t row = m0 + (lane & 31), col = n0 + (lane & 31);
   const int kk = lane >> 5;
+  // batch (blockIdx.y): the epilogue sees the batches stacked along the rows
+  g.A += (int64_t)blockIdx.y * g.a_batch;
+  g.B += (int64_t)blockIdx.y * g.b_batch;
+  const int64_t row_shift = (int64_t)blockIdx.y * g.M;
   // this wave's K range, a multiple of 16 long
   const int64_t quarter = ((g.K + 63) / 64) * 16;
   const int64_t k_begin = wave * quarter;
@@ -282,6 +339,18 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   const float* pa = g.A + (A_KC ? row * g.lda : row);
   const float* pb = g.B + (B_KC ? col * g.ldb : col);
   const int64_t sa = A_KC ? 1 : g.lda, sb = B_KC ? 1 : g.ldb;
+  constexpr bool kFetch = epi_elem_fetch<Epi>::value;
+  typename epi_fetched<Epi>::type fetched[kFetch ? 16 : 1];
+  if constexpr (kFetch) {
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (orow < g.M && col < g.N)
+          fetched[r] = epi.fetch(orow + row_shift, col);
+      }
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -308,7 +377,12 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
       const float v = (acc[r] + part[0][r][lane]) +
                       (part[1][r][lane] + part[2][r][lane]);
       const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (orow < g.M && col < g.N) epi(orow, col, v, 0);
+      if (orow < g.M && col < g.N) {
+        if constexpr (kFetch)
+          epi.apply(orow + row_shift, col, v, 0, fetched[r]);
+        else
+          epi(orow + row_shift, col, v, 0);
+      }
     }
   }
   epi.block_end();
@@ -343,10 +417,16 @@ static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
   g.b_batch = b_batch;
   const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
   if constexpr (!epi_whole_tile<Epi>::value) {
-    if (tiles <= 8 && k_slices == 1 && batches == 1) {
+    // few big tiles: a quarter of the CUs or fewer would work (the analysis
+    // contraction of the reference's convolutional example: 43 blocks)
+    // (batched products stay on the big kernel: measured 12.6 vs 20.4 us for
+    // the synthesis of that geometry, 90 tiles)
+    if ((tiles <= 8 || tiles * 2 <= gemm_compute_units()) && k_slices == 1 &&
+        batches == 1) {
       const int64_t small_tiles = ceil_div(M, 32) * ceil_div(N, 32);
       hipLaunchKernelGGL((gemm_f32_small_kernel<A_KC, B_KC, Epi>),
-                         dim3((unsigned)small_tiles), dim3(256), 0, st, g, epi);
+                         dim3((unsigned)small_tiles, (unsigned)batches),
+                         dim3(256), 0, st, g, epi);
       VTC_LAUNCH_CHECK();
       return VTC_OK;
     }
