@@ -25,8 +25,8 @@ def run(images_padded, dictionary, kernel_stride, padding_dims,
   (lead_h, trail_h)) or None.  Returns codes (b, s, code_h, code_w).
   Extensions: `stepsize` (skip the eigen-solve) and `precision` in {None,
   'auto', 'f32', 'f16x3', 'bf16x3'}.  The split modes run both convolutions as
-  hi/lo split contractions on the matrix cores (one channel, stride 1, square
-  kernels of 5/8/11/16): 'f16x3' in power-of-two scaled units with 11 + 11
+  hi/lo split contractions on the matrix cores (stride 1, square kernels of
+  5/8/11/16, one to four image channels): 'f16x3' in power-of-two scaled units with 11 + 11
   significand bits (float32-level results: 4e-6 from the reference's codes at
   T = 100, profiles/r03_precision_conv.txt), 'bf16x3' with 8 + 8 (1.8e-5).
   'auto' picks f16x3 where it applies and the direct f32 kernels elsewhere.

@@ -336,8 +336,12 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   const int64_t k_begin = wave * quarter;
   const int64_t k_end = k_begin + quarter < g.K ? k_begin + quarter : g.K;
   const bool row_ok = row < g.M, col_ok = col < g.N;
-  const float* pa = g.A + (A_KC ? row * g.lda : row);
-  const float* pb = g.B + (B_KC ? col * g.ldb : col);
+  // (addresses are clamped into the operand and the value masked afterwards:
+  // sixteen unconditional loads per step go out back to back, where a guarded
+  // load sits in a branch of its own)
+  const int64_t row_c = row_ok ? row : g.M - 1, col_c = col_ok ? col : g.N - 1;
+  const float* pa = g.A + (A_KC ? row_c * g.lda : row_c);
+  const float* pb = g.B + (B_KC ? col_c * g.ldb : col_c);
   const int64_t sa = A_KC ? 1 : g.lda, sb = B_KC ? 1 : g.ldb;
   constexpr bool kFetch = epi_elem_fetch<Epi>::value;
   typename epi_fetched<Epi>::type fetched[kFetch ? 16 : 1];
@@ -354,17 +358,53 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int64_t k0 = k_begin; k0 < k_end; k0 += 16) {
-    float a[8], b[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t k = k0 + 2 * j + kk;
-      a[j] = (row_ok && k < k_end) ? pa[k * sa] : 0.f;
-      b[j] = (col_ok && k < k_end) ? pb[k * sb] : 0.f;
+  // two steps of operands in flight: the loads of step i + 1 are issued
+  // before the products of step i
+  const int64_t k_last = k_end > k_begin ? k_end - 1 : k_begin;
+  // k of (product j, lane half kk) = k0 + 8 kk + j: a lane of a k-contiguous
+  // operand reads 8 consecutive floats -- two 16-byte loads instead of eight
+  // dwords that each touch 32 cache lines per wave (the kernel was bound by
+  // the address unit: 23 us for the 342 blocks of the convolutional example)
+  auto issue_operand = [&](const float* p, int64_t stride, bool kc_vec,
+                           int64_t k0, float (&v)[8]) {
+    const int64_t kb = k0 + 8 * kk;
+    if (kc_vec && kb + 8 <= k_end) {
+      const float4 lo = *reinterpret_cast<const float4*>(p + kb);
+      const float4 hi = *reinterpret_cast<const float4*>(p + kb + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+      v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      return;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = kb + j;
+      v[j] = p[(k < k_end ? k : k_last) * stride];
+    }
+  };
+  auto issue = [&](int64_t k0, float (&av)[8], float (&bv)[8]) {
+    issue_operand(pa, sa, A_KC && g.a_vec && (k_begin % 4 == 0), k0, av);
+    issue_operand(pb, sb, B_KC && g.b_vec && (k_begin % 4 == 0), k0, bv);
+  };
+  auto products = [&](int64_t k0, const float (&av)[8], const float (&bv)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool live = k0 + 8 * kk + j < k_end;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
+          (live && row_ok) ? av[j] : 0.f, (live && col_ok) ? bv[j] : 0.f, acc,
+          0, 0, 0);
+    }
+  };
+  if (k_begin < k_end) {
+    float a0[8], b0[8], a1[8], b1[8];
+    issue(k_begin, a0, b0);
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += 32) {
+      if (k0 + 16 < k_end) issue(k0 + 16, a1, b1);
+      products(k0, a0, b0);
+      if (k0 + 16 < k_end) {
+        if (k0 + 32 < k_end) issue(k0 + 32, a0, b0);
+        products(k0 + 16, a1, b1);
+      }
+    }
   }
   if (wave > 0) {
 #pragma unroll
