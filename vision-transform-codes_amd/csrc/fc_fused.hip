@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
   // hipcc would sink every dictionary load down to its consumer (to shorten
   // live ranges), which serialises load -> wait -> MFMA; the sched_barrier
   // after each k-step pins the issue order written here.
-  auto step3 = [&](int p, int buf, bool pipe, int sg) {
+  auto step3 = [&](int p, int buf, bool pipe, int sg, auto&& between) {
     uint4 yb_next[NP];
 #pragma unroll
     for (int part = 0; part < NP; ++part)
@@ -357,11 +357,15 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
           Racc[nb] = VTC_MFMA(a[0], yb[1], Racc[nb]);
           Racc[nb] = VTC_MFMA(a[1], yb[0], Racc[nb]);
         }
+        // (epilogue arithmetic of another phase, if any, before the refill:
+        // see step 1)
+        between(i);
         if (pipe) VTC_REFILL(sg, i)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+  auto nothing = [](int) {};
 
   // R_{k+1} = Racc - X  ->  bf16 parts -> LDS (read back as B fragments by
   // every wave during step 1 of the next iteration)
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
     for (int p = 0; p < NPH; ++p) {
       publish_y(Y[p], p & 1);
       __syncthreads();
-      step3(p, p & 1, false, 0);
+      step3(p, p & 1, false, 0, nothing);
     }
   }
   exchange_r();
@@ -590,15 +594,21 @@ __global__ __launch_bounds__(256, 1) void fused_fista_kernel(FusedParams P) {
       if (p + 1 < NPH) {
         step1(p + 1, 2 * p + 1, true, beta);   // + epilogue of phase p
         VTC_STAMP(0)
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) epilogue_elem(p, e, Gb[p & 1], beta);
-        VTC_STAMP(1)
       }
+      // (the epilogue of the LAST phase has no step 1 to hide under: it rides
+      // on step 3 of the phase before it -- its gradient tile is complete by
+      // then, and it writes the exchange buffer step 3 is not reading)
       __syncthreads();
       VTC_STAMP(2)
       // ---- step 3: next residual, this wave's 64 pixels
-      step3(p, p & 1, true, (p + 1 < NPH) ? 2 * p + 2 : 2 * NPH - 1);
+      if (p + 2 == NPH) {
+        step3(p, p & 1, true, 2 * p + 2, [&](int i) {
+          epilogue_elem(NPH - 1, i, Gb[(NPH - 1) & 1], beta);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
+        step3(p, p & 1, true, (p + 1 < NPH) ? 2 * p + 2 : 2 * NPH - 1, nothing);
+      }
       VTC_STAMP(3)
     }
     exchange_r();
