@@ -144,14 +144,24 @@ template <bool F16, int NP>
 __device__ __forceinline__ void split4(const float (&v)[4], uint2* hi_out,
                                        uint2* lo_out) {
   if (F16) {
-    f16x4 hi, lo;
+    // two values per instruction (v_cvt_pk_f16_f32, round to nearest even as
+    // the scalar conversion; v_pk_add_f32): the same arithmetic in fewer VALU
+    // instructions
+    typedef float pair_f32 __attribute__((ext_vector_type(2)));
+    typedef _Float16 pair_f16 __attribute__((ext_vector_type(2)));
+    unsigned hw[2], lw[2] = {0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      hi[k] = (_Float16)v[k];
-      if (NP == 2) lo[k] = (_Float16)(v[k] - (float)hi[k]);
+    for (int k = 0; k < 2; ++k) {
+      const pair_f32 x = {v[2 * k], v[2 * k + 1]};
+      const pair_f16 h = __builtin_convertvector(x, pair_f16);
+      hw[k] = __builtin_bit_cast(unsigned, h);
+      if (NP == 2)
+        lw[k] = __builtin_bit_cast(
+            unsigned, __builtin_convertvector(
+                          x - __builtin_convertvector(h, pair_f32), pair_f16));
     }
-    *hi_out = __builtin_bit_cast(uint2, hi);
-    if (NP == 2) *lo_out = __builtin_bit_cast(uint2, lo);
+    *hi_out = make_uint2(hw[0], hw[1]);
+    if (NP == 2) *lo_out = make_uint2(lw[0], lw[1]);
   } else {
     bf16x4 hi, lo;
 #pragma unroll
