@@ -92,18 +92,19 @@ def test_random_shapes_against_the_oracle(device, seed):
         if k % st: st = 1
         s = int(rs.choice([3, 8, 32, 40])); b = int(rs.choice([1, 2, 3]))
         h, w = int(rs.randint(20, 60)), int(rs.randint(20, 70))
+        cch = int(rs.choice([1, 1, 2, 3]))          # image channels
         lead = k - st
         H = ((h + 2 * lead - k + st - 1) // st) * st + k; W = ((w + 2 * lead - k + st - 1) // st) * st + k
-        imgs = np.zeros((b, 1, H, W), np.float32)
-        imgs[:, :, lead:lead + h, lead:lead + w] = 0.3 * rs.randn(b, 1, h, w)
+        imgs = np.zeros((b, cch, H, W), np.float32)
+        imgs[:, :, lead:lead + h, lead:lead + w] = 0.3 * rs.randn(b, cch, h, w)
         pad = ((lead, H - lead - h), (lead, W - lead - w))
-        D = unit(s, 1, k, k)
+        D = unit(s, cch, k, k)
         T = int(rs.choice([1, 4, 9])); step = 0.5 / s
         prec = 'auto'
         ref = sc_oracle.conv_ista_fista(torch.from_numpy(imgs), torch.from_numpy(D), (st, st), pad, 0.05, T, stepsize=step)
         out = conv.run(torch.from_numpy(imgs).to(dev), torch.from_numpy(D).to(dev), (st, st), pad, 0.05, T,
                        stepsize=step, precision=prec)
-        ok = check('conv b=%d s=%d k=%d st=%d %dx%d T=%d' % (b, s, k, st, H, W, T), out, ref, 1e-5, 2e-6)
+        ok = check('conv b=%d c=%d s=%d k=%d st=%d %dx%d T=%d' % (b, cch, s, k, st, H, W, T), out, ref, 1e-5, 2e-6)
     except Exception:
       report('case %d (%s): %s' % (c, kind, traceback.format_exc()))
   assert not failures, '\n'.join(failures)
