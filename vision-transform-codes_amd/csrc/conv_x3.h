@@ -476,7 +476,13 @@ struct __attribute__((packed, aligned(2))) CxUnaligned16 {
 // MA: 32-atom tiles per block (atom chunk AC = 32 * MA).  FAST: the common
 // case (FISTA, soft threshold, no early stopping) with every option folded at
 // compile time; the other instantiation reads them from ProxParams.
-template <int MA, bool FAST, bool F16>
+// SHIFT: the window is kept in 4 copies, copy c shifted by c pixels, and a lane
+// reads its 8 pixels as two 8-byte ALIGNED halves from copy (start & 3) -- the
+// unaligned 16-byte read costs 52-64 LDS cycles per wave against 4
+// (tools/micro/lds_unaligned.hip), and with one atom tile per block (colour
+// images: 32 atoms, 6 MFMAs per tap row) four of them per tap row made the
+// kernel LDS-bound five times over.  Chosen by the plan when the copies fit.
+template <int MA, bool FAST, bool F16, bool SHIFT>
 __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
@@ -489,6 +495,10 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   const int rows = ana_rows + k - 1;
   const int win = rows * kCxAnaPitch;              // elements per window plane
   // per image channel: kernel planes [hi | lo], then window planes [hi | lo]
+  // (SHIFT: 4 copies of [hi | lo | 32 elements of padding], which also puts
+  // the copies on disjoint banks)
+  const int wcopy = SHIFT ? 2 * win + 32 : 2 * win;
+  const int wchan = (SHIFT ? 4 : 1) * wcopy;       // elements per channel
   uint16_t* Dh = reinterpret_cast<uint16_t*>(lds);
   uint16_t* Dl = Dh + plane;
   uint16_t* Rh = Dh + 2 * plane * g.c;
@@ -528,13 +538,27 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     for (int i = tid; i < n16; i += 256) dst[i] = src[i];
     for (int channel = 0; channel < g.c; ++channel) {
       const float* Rimg = R + (img * g.c + channel) * g.H * (int64_t)g.W;
-      uint16_t* wh = Rh + channel * 2 * win;
+      uint16_t* wh = Rh + channel * wchan;
       for (int e = tid; e < win; e += 256) {
         const int ry = e / kCxAnaPitch, rx = e % kCxAnaPitch;
         const int y = u0 + ry, x = v0 + rx;
         const float v =
             (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
-        cx_split1<F16>(F16 ? v * r_scale : v, wh[e], wh[win + e]);
+        uint16_t hb, lb;
+        cx_split1<F16>(F16 ? v * r_scale : v, hb, lb);
+        if (SHIFT) {
+          // pixel x of a row sits at position x - c of copy c; the first c
+          // pixels of the window land in the padding of the copy before
+          // (never read: reads end at position 78 of a row of 88)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            wh[c * wcopy + e - c] = hb;
+            wh[c * wcopy + win + e - c] = lb;
+          }
+        } else {
+          wh[e] = hb;
+          wh[win + e] = lb;
+        }
       }
     }
   }
@@ -632,18 +656,32 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     // K index = (image channel, dy, 16 dx)
     for (int cdy = 0; cdy < g.c * k; ++cdy) {
       const int channel = cdy / k, dy = cdy - channel * k;
-      const int wbase = channel * 2 * win, dbase = channel * 2 * plane;
+      const int wbase = channel * wchan, dbase = channel * 2 * plane;
       uint4 bh[2], bl[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        const int off =
-            wbase + (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
-        const CxUnaligned16 h =
-            *reinterpret_cast<const CxUnaligned16*>(Rh + off);
-        const CxUnaligned16 l =
-            *reinterpret_cast<const CxUnaligned16*>(Rl + off);
-        bh[ni] = __builtin_bit_cast(uint4, h);
-        bl[ni] = __builtin_bit_cast(uint4, l);
+        if (SHIFT) {
+          // start = 32 ni + l31 + 8 half: copy (start & 3) = (l31 & 3), at
+          // position start - (start & 3): 8-byte aligned
+          const uint16_t* bp = Rh + wbase + (l31 & 3) * wcopy +
+                               (lu + dy) * kCxAnaPitch + 32 * ni + (l31 & ~3) +
+                               8 * half;
+          const uint2 h0 = *reinterpret_cast<const uint2*>(bp);
+          const uint2 h1 = *reinterpret_cast<const uint2*>(bp + 4);
+          const uint2 l0 = *reinterpret_cast<const uint2*>(bp + win);
+          const uint2 l1 = *reinterpret_cast<const uint2*>(bp + win + 4);
+          bh[ni] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          bl[ni] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else {
+          const int off =
+              wbase + (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
+          const CxUnaligned16 h =
+              *reinterpret_cast<const CxUnaligned16*>(Rh + off);
+          const CxUnaligned16 l =
+              *reinterpret_cast<const CxUnaligned16*>(Rl + off);
+          bh[ni] = __builtin_bit_cast(uint4, h);
+          bl[ni] = __builtin_bit_cast(uint4, l);
+        }
       }
 #pragma unroll
       for (int ma = 0; ma < MA; ++ma) {
@@ -1572,6 +1610,7 @@ struct CxPlan {
   int k, s16, syn_chunks, slots, AC, chunks;
   int syn_rows;      // code rows per wave of the synthesis kernel
   int ana_rows;      // code rows per block of the analysis kernel
+  bool ana_shift;    // aligned window copies (conv_analysis_x3_kernel<.., SHIFT>)
   size_t syn_image_bytes, ana_image_bytes;
   size_t syn_lds, ana_lds;
   int th, tw;
@@ -1661,8 +1700,17 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
                             ceil_div(g.ch, kCxAnaMaxRows) * p->chunks * g.b;
     p->ana_rows = blocks8 < (int64_t)16 * cx_compute_units() ? 4 : 8;
   }
-  p->ana_lds = g.c * ((size_t)2 * K * p->AC * 16 * 2 +
-                      (size_t)2 * (p->ana_rows + K - 1) * kCxAnaPitch * 2);
+  {
+    const size_t planes = (size_t)2 * K * p->AC * 16 * 2;
+    const size_t win = (size_t)(p->ana_rows + K - 1) * kCxAnaPitch;
+    const size_t plain = g.c * (planes + 2 * win * 2);
+    const size_t shifted = g.c * (planes + 4 * (2 * win + 32) * 2);
+    // aligned window copies when they fit and do not cost a resident block
+    const size_t budget = 150 * 1024, lds = 160 * 1024;
+    const size_t blocks_plain = lds / plain < 2 ? lds / plain : 2;
+    p->ana_shift = shifted <= budget && lds / shifted >= blocks_plain;
+    p->ana_lds = p->ana_shift ? shifted : plain;
+  }
   p->tw = Dm::TW;
   using F = CxFused<K>;
   p->synp_image_bytes = p->partial_bytes = p->fused_lds = 0;
@@ -1884,7 +1932,7 @@ static int cx_launch_synth(const float* Y, const uint16_t* syn, const float* X,
   return VTC_ERR_UNSUPPORTED;
 }
 
-template <int MA, bool FAST, bool F16>
+template <int MA, bool FAST, bool F16, bool SHIFT>
 static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 float* C, const ConvGeo& g, const CxPlan& p,
                                 const ProxParams& pp, const CxScales& sc,
@@ -1894,7 +1942,8 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
   static unsigned long long attr_set = 0;
   if (first_use_on_this_device(&attr_set)) {
     VTC_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(conv_analysis_x3_kernel<MA, FAST, F16>),
+        reinterpret_cast<const void*>(
+            conv_analysis_x3_kernel<MA, FAST, F16, SHIFT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   const int64_t bands = (int64_t)tiles_u * p.chunks * g.b;
@@ -1903,7 +1952,7 @@ static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
     set_error("conv bf16x3: too many tiles");
     return VTC_ERR_INVALID_ARGUMENT;
   }
-  hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST, F16>),
+  hipLaunchKernelGGL((conv_analysis_x3_kernel<MA, FAST, F16, SHIFT>),
                      dim3((unsigned)blocks), dim3(256), p.ana_lds, st, R, ana,
                      Y, C, g, tiles_v, tiles_u, p.chunks, p.ana_rows, pp, sc);
   VTC_LAUNCH_CHECK();
@@ -1916,14 +1965,18 @@ static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
                               hipStream_t st) {
   const bool fast = pp.fista && pp.mode == VTC_SOFT && !pp.delta_sum;
   const bool f16 = sc.dscale != nullptr;
+#define VTC_CX_ANA_S(MA_, FAST_, F16_)                                        \
+  (p.ana_shift ? cx_launch_analysis_m<MA_, FAST_, F16_, true>(R, ana, Y, C, g, \
+                                                              p, pp, sc, st)  \
+               : cx_launch_analysis_m<MA_, FAST_, F16_, false>(R, ana, Y, C,  \
+                                                               g, p, pp, sc,  \
+                                                               st))
 #define VTC_CX_ANA(MA_, FAST_)                                                \
-  (f16 ? cx_launch_analysis_m<MA_, FAST_, true>(R, ana, Y, C, g, p, pp, sc,   \
-                                                st)                           \
-       : cx_launch_analysis_m<MA_, FAST_, false>(R, ana, Y, C, g, p, pp, sc,  \
-                                                 st))
+  (f16 ? VTC_CX_ANA_S(MA_, FAST_, true) : VTC_CX_ANA_S(MA_, FAST_, false))
   if (p.AC == 64) return fast ? VTC_CX_ANA(2, true) : VTC_CX_ANA(2, false);
   return fast ? VTC_CX_ANA(1, true) : VTC_CX_ANA(1, false);
 #undef VTC_CX_ANA
+#undef VTC_CX_ANA_S
 }
 
 // blocks of the gradient kernel (and slabs of its output)
