@@ -476,13 +476,15 @@ struct __attribute__((packed, aligned(2))) CxUnaligned16 {
 // MA: 32-atom tiles per block (atom chunk AC = 32 * MA).  FAST: the common
 // case (FISTA, soft threshold, no early stopping) with every option folded at
 // compile time; the other instantiation reads them from ProxParams.
-// SHIFT: the window is kept in 4 copies, copy c shifted by c pixels, and a lane
-// reads its 8 pixels as two 8-byte ALIGNED halves from copy (start & 3) -- the
-// unaligned 16-byte read costs 52-64 LDS cycles per wave against 4
+// SHIFT = 4 or 2: the window is kept in that many copies, copy c shifted by c
+// pixels, and a lane reads its 8 pixels from copy (start mod SHIFT) at an
+// 8-byte (4 copies) or 4-byte (2 copies) ALIGNED position -- the unaligned
+// 16-byte read costs 52-64 LDS cycles per wave against 4
 // (tools/micro/lds_unaligned.hip), and with one atom tile per block (colour
 // images: 32 atoms, 6 MFMAs per tap row) four of them per tap row made the
-// kernel LDS-bound five times over.  Chosen by the plan when the copies fit.
-template <int MA, bool FAST, bool F16, bool SHIFT>
+// kernel LDS-bound five times over.  SHIFT = 1: one copy, unaligned reads.
+// Chosen by the plan: as many copies as fit without costing a resident block.
+template <int MA, bool FAST, bool F16, int SHIFT>
 __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
     const float* __restrict__ R, const uint16_t* __restrict__ ana_image,
     float* __restrict__ Y, float* __restrict__ C, ConvGeo g, int tiles_v,
@@ -497,8 +499,8 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
   // per image channel: kernel planes [hi | lo], then window planes [hi | lo]
   // (SHIFT: 4 copies of [hi | lo | 32 elements of padding], which also puts
   // the copies on disjoint banks)
-  const int wcopy = SHIFT ? 2 * win + 32 : 2 * win;
-  const int wchan = (SHIFT ? 4 : 1) * wcopy;       // elements per channel
+  const int wcopy = SHIFT > 1 ? 2 * win + 32 : 2 * win;
+  const int wchan = SHIFT * wcopy;                 // elements per channel
   uint16_t* Dh = reinterpret_cast<uint16_t*>(lds);
   uint16_t* Dl = Dh + plane;
   uint16_t* Rh = Dh + 2 * plane * g.c;
@@ -546,12 +548,12 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
             (y < g.H && x < g.W) ? Rimg[(int64_t)y * g.W + x] : 0.f;
         uint16_t hb, lb;
         cx_split1<F16>(F16 ? v * r_scale : v, hb, lb);
-        if (SHIFT) {
+        if (SHIFT > 1) {
           // pixel x of a row sits at position x - c of copy c; the first c
           // pixels of the window land in the padding of the copy before
           // (never read: reads end at position 78 of a row of 88)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < SHIFT; ++c) {
             wh[c * wcopy + e - c] = hb;
             wh[c * wcopy + win + e - c] = lb;
           }
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
       uint4 bh[2], bl[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
-        if (SHIFT) {
+        if (SHIFT == 4) {
           // start = 32 ni + l31 + 8 half: copy (start & 3) = (l31 & 3), at
           // position start - (start & 3): 8-byte aligned
           const uint16_t* bp = Rh + wbase + (l31 & 3) * wcopy +
@@ -672,6 +674,15 @@ __global__ __launch_bounds__(256) void conv_analysis_x3_kernel(
           const uint2 l1 = *reinterpret_cast<const uint2*>(bp + win + 4);
           bh[ni] = make_uint4(h0.x, h0.y, h1.x, h1.y);
           bl[ni] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        } else if (SHIFT == 2) {
+          // copy (l31 & 1), position start - (start & 1): 4-byte aligned, four
+          // dword reads per plane (ds_read2_b32 pairs)
+          const uint32_t* bp = reinterpret_cast<const uint32_t*>(
+              Rh + wbase + (l31 & 1) * wcopy + (lu + dy) * kCxAnaPitch +
+              32 * ni + (l31 & ~1) + 8 * half);
+          const uint32_t* lp = bp + win / 2;
+          bh[ni] = make_uint4(bp[0], bp[1], bp[2], bp[3]);
+          bl[ni] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
         } else {
           const int off =
               wbase + (lu + dy) * kCxAnaPitch + 32 * ni + l31 + 8 * half;
@@ -1610,7 +1621,7 @@ struct CxPlan {
   int k, s16, syn_chunks, slots, AC, chunks;
   int syn_rows;      // code rows per wave of the synthesis kernel
   int ana_rows;      // code rows per block of the analysis kernel
-  bool ana_shift;    // aligned window copies (conv_analysis_x3_kernel<.., SHIFT>)
+  int ana_shift;     // window copies (conv_analysis_x3_kernel<.., SHIFT>): 1, 2, 4
   size_t syn_image_bytes, ana_image_bytes;
   size_t syn_lds, ana_lds;
   int th, tw;
@@ -1707,9 +1718,17 @@ static void cx_fill_plan(const ConvGeo& g, CxPlan* p) {
     const size_t shifted = g.c * (planes + 4 * (2 * win + 32) * 2);
     // aligned window copies when they fit and do not cost a resident block
     const size_t budget = 150 * 1024, lds = 160 * 1024;
+    const size_t two = g.c * (planes + 2 * (2 * win + 32) * 2);
     const size_t blocks_plain = lds / plain < 2 ? lds / plain : 2;
-    p->ana_shift = shifted <= budget && lds / shifted >= blocks_plain;
-    p->ana_lds = p->ana_shift ? shifted : plain;
+    p->ana_shift = 1;
+    p->ana_lds = plain;
+    if (shifted <= budget && lds / shifted >= blocks_plain) {
+      p->ana_shift = 4;
+      p->ana_lds = shifted;
+    } else if (two <= budget && lds / two >= blocks_plain) {
+      p->ana_shift = 2;
+      p->ana_lds = two;
+    }
   }
   p->tw = Dm::TW;
   using F = CxFused<K>;
@@ -1932,7 +1951,7 @@ static int cx_launch_synth(const float* Y, const uint16_t* syn, const float* X,
   return VTC_ERR_UNSUPPORTED;
 }
 
-template <int MA, bool FAST, bool F16, bool SHIFT>
+template <int MA, bool FAST, bool F16, int SHIFT>
 static int cx_launch_analysis_m(const float* R, const uint16_t* ana, float* Y,
                                 float* C, const ConvGeo& g, const CxPlan& p,
                                 const ProxParams& pp, const CxScales& sc,
@@ -1966,11 +1985,14 @@ static int cx_launch_analysis(const float* R, const uint16_t* ana, float* Y,
   const bool fast = pp.fista && pp.mode == VTC_SOFT && !pp.delta_sum;
   const bool f16 = sc.dscale != nullptr;
 #define VTC_CX_ANA_S(MA_, FAST_, F16_)                                        \
-  (p.ana_shift ? cx_launch_analysis_m<MA_, FAST_, F16_, true>(R, ana, Y, C, g, \
-                                                              p, pp, sc, st)  \
-               : cx_launch_analysis_m<MA_, FAST_, F16_, false>(R, ana, Y, C,  \
-                                                               g, p, pp, sc,  \
-                                                               st))
+  (p.ana_shift == 4                                                           \
+       ? cx_launch_analysis_m<MA_, FAST_, F16_, 4>(R, ana, Y, C, g, p, pp, sc, \
+                                                   st)                        \
+       : p.ana_shift == 2                                                     \
+             ? cx_launch_analysis_m<MA_, FAST_, F16_, 2>(R, ana, Y, C, g, p,  \
+                                                         pp, sc, st)          \
+             : cx_launch_analysis_m<MA_, FAST_, F16_, 1>(R, ana, Y, C, g, p,  \
+                                                         pp, sc, st))
 #define VTC_CX_ANA(MA_, FAST_)                                                \
   (f16 ? VTC_CX_ANA_S(MA_, FAST_, true) : VTC_CX_ANA_S(MA_, FAST_, false))
   if (p.AC == 64) return fast ? VTC_CX_ANA(2, true) : VTC_CX_ANA(2, false);
