@@ -395,7 +395,10 @@ __global__ __launch_bounds__(kLzThreads) void lanczos_lambda_max_kernel(
   if (converged || !(lambda == lambda) || steps >= k_cap) break;
   __syncthreads();
   if (tid == 0) beta2[steps - 1] = coupling;
-  target = steps + kLzExtend < k_cap ? steps + kLzExtend : k_cap;
+  {
+    const int more = steps / 2 > kLzExtend ? steps / 2 : kLzExtend;
+    target = steps + more < k_cap ? steps + more : k_cap;
+  }
   __syncthreads();
   }
   const float lf = (float)lambda;
@@ -605,7 +608,12 @@ static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
   // Small matrices get n + 16 steps (steps past n only breed copies of
   // converged Ritz values), so that the look-back comparison has a converged
   // prefix to look at.
-  constexpr int kSteps = 96;
+  // Round 3: the kernel reports convergence itself, so the first look comes at
+  // 48 steps (random-dictionary Gram matrices of 256 to 1024 atoms have
+  // converged by 24 to 48: 7e-9 from the float64 value) and later ones after
+  // half as many steps again -- 48, 72, 108, 162, 243 --, each costing one
+  // sectioning pass (19 us).
+  constexpr int kSteps = 48;
   const int64_t want = 2 * n > n + 16 ? 2 * n : n + 16;
   const int64_t most = 2 * n > n + 48 ? 2 * n : n + 48;
   int k_small = (int)(want < kSteps ? want : kSteps);
