@@ -164,6 +164,28 @@ struct EpiPatchProx {
   }
 };
 
+// The im2col view as a B operand source of gemm_f32_small_kernel: element
+// (pos, t) = R[img][chan][p*sv + dy][q*sh + dx], read in place.
+struct BIm2col {
+  const float* R;
+  int c, H, W, kh, kw, sv, sh, ch, cw;
+  int vec;   // 8 consecutive t of a lane are 8 consecutive, 16-byte aligned
+             // pixels (kw % 8 == 0, strides and rows multiples of 4 floats)
+  __device__ __forceinline__ const float* row(int64_t pos) const {
+    const unsigned p32 = (unsigned)pos;
+    const unsigned q = p32 % (unsigned)cw, pc = p32 / (unsigned)cw;
+    const unsigned p = pc % (unsigned)ch, img = pc / (unsigned)ch;
+    return R + ((int64_t)img * c * H + (int64_t)p * sv) * W + q * sh;
+  }
+  __device__ __forceinline__ const float* at(const float* base,
+                                             int64_t k) const {
+    const unsigned t = (unsigned)k;
+    const unsigned dx = t % (unsigned)kw, rest = t / (unsigned)kw;
+    const unsigned dy = rest % (unsigned)kh, chan = rest / (unsigned)kh;
+    return base + ((int64_t)chan * H + dy) * W + dx;
+  }
+};
+
 static unsigned patch_grid(int64_t total) {
   int64_t blocks = ceil_div(total, 256);
   if (blocks > 8192) blocks = 8192;
@@ -195,11 +217,23 @@ static int patch_analysis(const float* residual, const float* D, float* Y,
                           const ProxParams& pp, hipStream_t st) {
   const int64_t map = (int64_t)g.ch * g.cw;
   const int64_t ctaps = (int64_t)g.c * g.kh * g.kw;
+  EpiPatchProx e{Y, C, g.s, map, pp, 0.0};
+  // Few tiles (the reference's example: 64 kernels, 5 images): the 32x32-tile
+  // kernel reads the patches straight from the residual image -- no im2col
+  // pass, no patch matrix in memory (9.5 of 43 us per iteration there).
+  {
+    BIm2col src{residual, g.c, g.H, g.W, g.kh, g.kw, g.sv, g.sh, g.ch, g.cw, 0};
+    src.vec = (g.kw % 8 == 0 && g.sh % 4 == 0 && g.W % 4 == 0 &&
+               (reinterpret_cast<uintptr_t>(residual) & 15) == 0)
+                  ? 1 : 0;
+    const int rc = launch_gemm_f32_small_mapped(D, ctaps, (int64_t)g.s,
+                                                g.b * map, ctaps, e, src, st);
+    if (rc != VTC_ERR_UNSUPPORTED) return rc;
+  }
   hipLaunchKernelGGL(conv_im2col_kernel, dim3(patch_grid(g.b * map * ctaps)),
                      dim3(256), 0, st, residual, P, g);
   VTC_LAUNCH_CHECK();
   // G[s, pos] = sum_t D[s, t] P[pos, t]: both operands k-contiguous
-  EpiPatchProx e{Y, C, g.s, map, pp, 0.0};
   return launch_gemm_f32<true, true>(D, ctaps, P, ctaps, g.s, g.b * map, ctaps,
                                      1, e, st);
 }

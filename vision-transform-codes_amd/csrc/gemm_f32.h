@@ -317,9 +317,18 @@ static inline int gemm_vec_ok(const float* p, int64_t ld) {
 // operands go from L2 straight into the MFMA operand registers (one float per
 // lane and product), and the four partial tiles are summed through LDS in wave
 // order (bitwise reproducible).  Element-wise epilogues only.
-template <bool A_KC, bool B_KC, class Epi>
+// B operand sources of the small kernel.  BPlain: g.B as GemmArgs declares it.
+// A source with `row(col)` / `at(base, k)` maps element (col, k) of a k-major
+// operand onto memory itself -- the im2col view of the strided convolution
+// (conv_patch.h) reads the residual image in place, no patch matrix in HBM.
+struct BPlain {};
+template <class B>
+struct b_is_plain : std::is_same<B, BPlain> {};
+
+template <bool A_KC, bool B_KC, class Epi, class BSrc = BPlain>
 __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
-                                                             Epi epi) {
+                                                             Epi epi,
+                                                             BSrc bsrc = BSrc()) {
   __shared__ float part[3][16][64];
   resolve_epilogue(epi, 0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   const int64_t row_c = row_ok ? row : g.M - 1, col_c = col_ok ? col : g.N - 1;
   const float* pa = g.A + (A_KC ? row_c * g.lda : row_c);
   const float* pb = g.B + (B_KC ? col_c * g.ldb : col_c);
+  if constexpr (!b_is_plain<BSrc>::value) pb = bsrc.row(col_c);
   const int64_t sa = A_KC ? 1 : g.lda, sb = B_KC ? 1 : g.ldb;
   constexpr bool kFetch = epi_elem_fetch<Epi>::value;
   typename epi_fetched<Epi>::type fetched[kFetch ? 16 : 1];
@@ -383,7 +393,26 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs g,
   };
   auto issue = [&](int64_t k0, float (&av)[8], float (&bv)[8]) {
     issue_operand(pa, sa, A_KC && g.a_vec && (k_begin % 4 == 0), k0, av);
-    issue_operand(pb, sb, B_KC && g.b_vec && (k_begin % 4 == 0), k0, bv);
+    if constexpr (b_is_plain<BSrc>::value) {
+      issue_operand(pb, sb, B_KC && g.b_vec && (k_begin % 4 == 0), k0, bv);
+    } else {
+      // mapped operand: 8 consecutive k of a lane are contiguous in memory
+      // when the source says so (two 16-byte loads), else element by element
+      const int64_t kb = k0 + 8 * kk;
+      if (bsrc.vec && kb + 8 <= k_end) {
+        const float* p8 = bsrc.at(pb, kb);
+        const float4 lo = *reinterpret_cast<const float4*>(p8);
+        const float4 hi = *reinterpret_cast<const float4*>(p8 + 4);
+        bv[0] = lo.x; bv[1] = lo.y; bv[2] = lo.z; bv[3] = lo.w;
+        bv[4] = hi.x; bv[5] = hi.y; bv[6] = hi.z; bv[7] = hi.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t k = kb + j;
+          bv[j] = *bsrc.at(pb, k < k_end ? k : k_last);
+        }
+      }
+    }
   };
   auto products = [&](int64_t k0, const float (&av)[8], const float (&bv)[8]) {
 #pragma unroll
@@ -478,6 +507,38 @@ static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
   dim3 grid((unsigned)tiles, (unsigned)k_slices, (unsigned)batches);
   hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, Epi>), grid,
                      dim3(kGemmThreads), 0, st, g, epi);
+  VTC_LAUNCH_CHECK();
+  return VTC_OK;
+}
+
+// C[M,N] = A[M,K] * Bsrc(N,K)^T on the small kernel, the B operand read
+// through `bsrc` (see BPlain).  Returns VTC_ERR_UNSUPPORTED when the problem
+// is not one for the small kernel (the caller then materialises B).
+template <class Epi, class BSrc>
+static int launch_gemm_f32_small_mapped(const float* A, int64_t lda, int64_t M,
+                                        int64_t N, int64_t K, Epi epi,
+                                        BSrc bsrc, hipStream_t st) {
+  if (M <= 0 || N <= 0) return VTC_OK;
+  const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
+  const int64_t small_tiles = ceil_div(M, 32) * ceil_div(N, 32);
+  if (!(tiles <= 8 || tiles * 2 <= gemm_compute_units()) ||
+      small_tiles > 0x7fffffffLL)
+    return VTC_ERR_UNSUPPORTED;
+  GemmArgs g;
+  g.A = A;
+  g.B = nullptr;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = 0;
+  g.k_chunk = K;
+  g.a_vec = gemm_vec_ok(A, lda);
+  g.b_vec = 0;
+  g.a_batch = g.b_batch = 0;
+  hipLaunchKernelGGL((gemm_f32_small_kernel<true, true, Epi, BSrc>),
+                     dim3((unsigned)small_tiles), dim3(256), 0, st, g, epi,
+                     bsrc);
   VTC_LAUNCH_CHECK();
   return VTC_OK;
 }
