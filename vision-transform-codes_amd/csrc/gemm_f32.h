@@ -305,6 +305,12 @@ static int gemm_compute_units() {
   return cus;
 }
 
+static bool gemm_prefers_small(int64_t M, int64_t N) {
+  const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
+  const double full_tiles = (double)M * (double)N / (kGemmBM * kGemmBN);
+  return tiles <= 8 || full_tiles <= (double)gemm_compute_units();
+}
+
 static inline int gemm_vec_ok(const float* p, int64_t ld) {
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0) ? 1 : 0;
 }
@@ -486,12 +492,15 @@ static int launch_gemm_f32(const float* A, int64_t lda, const float* B,
   g.b_batch = b_batch;
   const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
   if constexpr (!epi_whole_tile<Epi>::value) {
-    // few big tiles: a quarter of the CUs or fewer would work (the analysis
-    // contraction of the reference's convolutional example: 43 blocks)
-    // (batched products stay on the big kernel: measured 12.6 vs 20.4 us for
-    // the synthesis of that geometry, 90 tiles)
-    if ((tiles <= 8 || tiles * 2 <= gemm_compute_units()) && k_slices == 1 &&
-        batches == 1) {
+    // Few big tiles (the analysis contraction of the reference's
+    // convolutional example: 43 blocks on 256 CUs), or tiles that are mostly
+    // empty (N = 64 or 144 output columns): the 32x32-tile kernel when the
+    // output amounts to no more full 128x128 tiles than there are CUs.
+    // Measured on f32 FISTA runs of mid-size shapes: 1.6-2.8x below a quarter
+    // of the chip, 7-18 % up to one tile per CU, 8 % SLOWER at two full tiles
+    // per CU.  (Batched products stay on the big kernel: 12.6 vs 20.4 us for
+    // the synthesis of that geometry, 90 tiles.)
+    if (gemm_prefers_small(M, N) && k_slices == 1 && batches == 1) {
       const int64_t small_tiles = ceil_div(M, 32) * ceil_div(N, 32);
       hipLaunchKernelGGL((gemm_f32_small_kernel<A_KC, B_KC, Epi>),
                          dim3((unsigned)small_tiles, (unsigned)batches),
@@ -519,10 +528,8 @@ static int launch_gemm_f32_small_mapped(const float* A, int64_t lda, int64_t M,
                                         int64_t N, int64_t K, Epi epi,
                                         BSrc bsrc, hipStream_t st) {
   if (M <= 0 || N <= 0) return VTC_OK;
-  const int64_t tiles = ceil_div(M, kGemmBM) * ceil_div(N, kGemmBN);
   const int64_t small_tiles = ceil_div(M, 32) * ceil_div(N, 32);
-  if (!(tiles <= 8 || tiles * 2 <= gemm_compute_units()) ||
-      small_tiles > 0x7fffffffLL)
+  if (!gemm_prefers_small(M, N) || small_tiles > 0x7fffffffLL)
     return VTC_ERR_UNSUPPORTED;
   GemmArgs g;
   g.A = A;
