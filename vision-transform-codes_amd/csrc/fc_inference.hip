@@ -219,7 +219,9 @@ static int run_generic(const float* images, const float* dictionary,
     const bool wide_ok = s % 4 == 0 &&
                          (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(codes) & 15) == 0;
-    if (x3 || wide_ok) {
+    // (few-tile products take the 32x32-tile kernel with the element-wise
+    // epilogue: 40 blocks of the whole-tile epilogue leave most CUs idle)
+    if (x3 || (wide_ok && !gemm_prefers_small(b, s))) {
       // 16-byte, pipelined epilogue (epi_prox.h); in ISTA Y and the codes are
       // one buffer and both stores carry the same value
       EpiGroupProx<1, true> e2{Y, Cin, s, eta, cutoff,
