@@ -120,7 +120,11 @@ def _resolve_precision(precision, b, n, s, early_stopping_epsilon):
     # (bf16x3, 1.75e-5, stays available by name and is never the default.)
     fused_ok = (early_stopping_epsilon is None and n == 256 and
                 s in (256, 512, 1024) and fused_available())
-    tiled_ok = (n % 4 == 0 and s % 4 == 0 and b * s >= (1 << 22) and
+    # (cut-over measured on one MI355X, T = 50: below ~2.4e8 multiply-adds per
+    # product the 32x32-tile exact-f32 kernels win -- 1536 x 144 x 640: 1.6 vs
+    # 1.9 ms, 600 x 400 x 1000: 2.1 vs 2.5 --, above it the split tiles --
+    # 4096 x 400 x 1000: 3.7 vs 7.0, 3072 x 144 x 640: 2.1 vs 2.3)
+    tiled_ok = (n % 4 == 0 and s % 4 == 0 and b * s * n >= 240000000 and
                 fused_available())
     streamed_ok = (early_stopping_epsilon is None and n == 256 and
                    s > 1024 and s % 256 == 0 and fused_available())
