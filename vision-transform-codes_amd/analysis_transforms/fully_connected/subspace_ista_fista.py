@@ -25,9 +25,11 @@ def run(images, dictionary, group_assignments, sparsity_weight,
   Returns codes (b, s); an atom that belongs to several groups gets the sum of
   its per-group coefficients (ret_summed_gduplicates=True, the only mode the
   reference implements).  Extensions: `stepsize` (skip the eigen-solve) and
-  `precision` in {None, 'auto', 'f32', 'bf16x3'}: 'auto' (the default policy)
-  uses the bf16 hi/lo split contraction for large problems (>= 1024 slots)
-  and the exact-f32 one otherwise.
+  `precision` in {None, 'auto', 'f32', 'f16x3', 'bf16x3'}: 'auto' (the default
+  policy) uses the f16 hi/lo split (float32-level results) on the fused
+  streamed kernel (16x16 patches) and on the tiled contractions for large
+  problems (>= 1024 slots, groups of a power of two), the exact-f32 kernels
+  otherwise.
   """
   assert variant in ['ista', 'fista']
   if hard_threshold:

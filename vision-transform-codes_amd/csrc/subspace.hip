@@ -34,6 +34,18 @@ struct EpiGradStep {  // Yo <- Y - eta * g  (out of place, see epi_prox.h)
     const int64_t i = row * ld + col;
     Yo[i] = sub_rn(Y[i], mul_rn(eta, g));
   }
+  // exact-f32 kernels (gemm_f32.h): Y is read before the K loop
+  static constexpr bool kElemFetch = true;
+  struct Fetched {
+    float y;
+  };
+  __device__ __forceinline__ Fetched fetch(int64_t row, int64_t col) const {
+    return Fetched{Y[row * ld + col]};
+  }
+  __device__ __forceinline__ void apply(int64_t row, int64_t col, float g, int,
+                                        const Fetched& f) const {
+    Yo[row * ld + col] = sub_rn(f.y, mul_rn(eta, g));
+  }
   __device__ __forceinline__ void block_end() const {}
 };
 
@@ -492,7 +504,10 @@ extern "C" int vtc_subspace_ista_fista(
     const bool wide_ok = slots % 4 == 0 &&
                          (reinterpret_cast<uintptr_t>(Y) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(grouped_codes) & 15) == 0;
-    if (wide_ok) {
+    // (exact f32, few tiles: the 32x32-tile kernel with the element-wise
+    // gradient step and the separate proximal kernel beats a handful of
+    // blocks of the whole-tile epilogue)
+    if (wide_ok && (x3 || !gemm_prefers_small(b, slots))) {
 #define VTC_FUSED_PROX(MM)                                                  \
   case MM:                                                                  \
     rc = launch_grad_prox<MM>(x3, R, grouped_dictionary, Y, Cin, Yout,     \
