@@ -331,7 +331,15 @@ extern "C" int vtc_fc_dict_gradient(const float* images,
   int rc = launch_gemm_f32<true, false>(codes, s, dictionary, n, b, n, s, 1,
                                         e1, st);
   if (rc != VTC_OK) return rc;
-  // G = C^T E, K = b split into slabs
+  // G = C^T E.  Small batches of a small dictionary (the reference's example
+  // sizes: 250 patches, 256 atoms): one launch of the 32x32-tile kernel
+  // straight into grad_sum -- no slabs, no reduction pass.
+  if (b <= 512 && gemm_prefers_small(s, n)) {
+    EpiStore direct{grad_sum, n};
+    return launch_gemm_f32<false, false>(codes, s, E, n, s, n, b, 1, direct,
+                                         st);
+  }
+  // otherwise K = b split into slabs
   EpiSlab e2{slabs, s * n, n};
   rc = launch_gemm_f32<false, false>(codes, s, E, n, s, n, b, slices, e2, st);
   if (rc != VTC_OK) return rc;
