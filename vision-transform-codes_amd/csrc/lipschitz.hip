@@ -609,11 +609,11 @@ static int lambda_max_impl(const float* symmetric, int64_t n, float* out,
   // converged Ritz values), so that the look-back comparison has a converged
   // prefix to look at.
   // Round 3: the kernel reports convergence itself, so the first look comes at
-  // 48 steps (random-dictionary Gram matrices of 256 to 1024 atoms have
+  // 32 steps (random-dictionary Gram matrices of 256 to 1024 atoms have
   // converged by 24 to 48: 7e-9 from the float64 value) and later ones after
-  // half as many steps again -- 48, 72, 108, 162, 243 --, each costing one
-  // sectioning pass (19 us).
-  constexpr int kSteps = 48;
+  // half as many steps again, at least 16 -- 32, 48, 72, 108, 162, 243 --,
+  // each costing one sectioning pass (18 us).
+  constexpr int kSteps = 32;
   const int64_t want = 2 * n > n + 16 ? 2 * n : n + 16;
   const int64_t most = 2 * n > n + 48 ? 2 * n : n + 48;
   int k_small = (int)(want < kSteps ? want : kSteps);
