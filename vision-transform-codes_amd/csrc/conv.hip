@@ -808,6 +808,11 @@ extern "C" size_t vtc_conv_dict_gradient_workspace_bytes(
     if ((size_t)cx_grad_blocks(g) > slab_count) slab_count = cx_grad_blocks(g);
     extra = cx_image_bytes(xp);
   }
+  // strided geometries: the residual comes from the patch contraction
+  // (conv_patch.h), which needs its per-position contributions Q
+  if (patch_geometry(g))
+    extra += align_up((size_t)g.b * g.ch * g.cw * g.c * g.kh * g.kw *
+                          sizeof(float), 256);
   return align_up((size_t)g.b * g.c * g.H * g.W * sizeof(float), 256) +
          align_up(slab_count * g.s * g.c * g.kh * g.kw * sizeof(float), 256) +
          extra;
@@ -873,7 +878,14 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
     return launch_slab_reduce(xslabs, xblocks, dict_elems, grad_sum, st);
   }
   float* slabs = ws.take<float>((size_t)blocks * dict_elems);
-  rc = launch_synthesis(codes, dictionary, images_padded, residual, g, st);
+  if (patch_geometry(g)) {
+    // (the direct synthesis kernel spends ~30 integer instructions per FMA on
+    // strided geometries: 135 us against 19 at the reference's example size)
+    float* Q = ws.take<float>((size_t)g.b * g.ch * g.cw * g.c * g.kh * g.kw);
+    rc = patch_synthesis(codes, dictionary, images_padded, residual, Q, g, st);
+  } else {
+    rc = launch_synthesis(codes, dictionary, images_padded, residual, g, st);
+  }
   if (rc != VTC_OK) return rc;
   const size_t lds = ap.lds_bytes +
                      (size_t)kAnaAcc * ap.tp * ap.tq * sizeof(float);
