@@ -802,6 +802,7 @@ extern "C" size_t vtc_conv_dict_gradient_workspace_bytes(
   const int64_t tiles =
       g.b * ceil_div(g.ch, ap.tp) * ceil_div(g.cw, ap.tq);
   size_t slab_count = (size_t)grad_blocks(tiles);
+  if (patch_gradient_small(g) && slab_count < (size_t)g.b) slab_count = g.b;
   size_t extra = 0;
   CxPlan xp;
   if (cx_plan(g, &xp)) {                            // bf16x3 route
@@ -877,7 +878,9 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
     if (rc != VTC_OK) return rc;
     return launch_slab_reduce(xslabs, xblocks, dict_elems, grad_sum, st);
   }
-  float* slabs = ws.take<float>((size_t)blocks * dict_elems);
+  float* slabs = ws.take<float>(
+      (size_t)(patch_gradient_small(g) && blocks < g.b ? g.b : blocks) *
+      dict_elems);
   if (patch_geometry(g)) {
     // (the direct synthesis kernel spends ~30 integer instructions per FMA on
     // strided geometries: 135 us against 19 at the reference's example size)
@@ -887,6 +890,12 @@ extern "C" int vtc_conv_dict_gradient(const float* images_padded,
     rc = launch_synthesis(codes, dictionary, images_padded, residual, g, st);
   }
   if (rc != VTC_OK) return rc;
+  if (patch_gradient_small(g)) {
+    // one slab per image (the workspace holds at least b of them)
+    rc = patch_gradient_slabs(residual, codes, slabs, g, st);
+    if (rc != VTC_OK) return rc;
+    return launch_slab_reduce(slabs, (int)g.b, dict_elems, grad_sum, st);
+  }
   const size_t lds = ap.lds_bytes +
                      (size_t)kAnaAcc * ap.tp * ap.tq * sizeof(float);
   hipLaunchKernelGGL(conv_grad_kernel, dim3((unsigned)blocks), dim3(256), lds,

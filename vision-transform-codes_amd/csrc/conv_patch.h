@@ -186,6 +186,51 @@ struct BIm2col {
   }
 };
 
+// The transposed view for the dictionary gradient of ONE image: element
+// (tap t, position k) = R_img[chan][p*sv + dy][q*sh + dx], k = p*cw + q.
+struct BIm2colT {
+  const float* Rimg;
+  int H, W, kh, kw, sv, sh, cw;
+  int vec;   // 0: consecutive positions are `sh` pixels apart
+  __device__ __forceinline__ const float* row(int64_t tap) const {
+    const unsigned t = (unsigned)tap;
+    const unsigned dx = t % (unsigned)kw, rest = t / (unsigned)kw;
+    const unsigned dy = rest % (unsigned)kh, chan = rest / (unsigned)kh;
+    return Rimg + ((int64_t)chan * H + dy) * W + dx;
+  }
+  __device__ __forceinline__ const float* at(const float* base,
+                                             int64_t k) const {
+    const unsigned k32 = (unsigned)k;
+    const unsigned p = k32 / (unsigned)cw, q = k32 - p * (unsigned)cw;
+    return base + (int64_t)(p * sv) * W + q * sh;
+  }
+};
+
+// few images, small dictionary: the gradient per image on the 32x32-tile kernel
+static bool patch_gradient_small(const ConvGeo& g) {
+  return patch_geometry(g) && g.b <= 16 &&
+         gemm_prefers_small(g.s, (int64_t)g.c * g.kh * g.kw);
+}
+
+// slabs[img][s][t] = sum_pos C[img][s][pos] * P[img][pos][t], the patches read
+// in place from the residual
+static int patch_gradient_slabs(const float* residual, const float* codes,
+                                float* slabs, const ConvGeo& g,
+                                hipStream_t st) {
+  const int64_t map = (int64_t)g.ch * g.cw;
+  const int64_t ctaps = (int64_t)g.c * g.kh * g.kw;
+  for (int64_t img = 0; img < g.b; ++img) {
+    BIm2colT src{residual + img * g.c * g.H * (int64_t)g.W, g.H, g.W, g.kh,
+                 g.kw, g.sv, g.sh, g.cw, 0};
+    EpiStore e{slabs + img * g.s * ctaps, ctaps};
+    const int rc = launch_gemm_f32_small_mapped(codes + img * g.s * map, map,
+                                                (int64_t)g.s, ctaps, map, e,
+                                                src, st);
+    if (rc != VTC_OK) return rc;
+  }
+  return VTC_OK;
+}
+
 static unsigned patch_grid(int64_t total) {
   int64_t blocks = ceil_div(total, 256);
   if (blocks > 8192) blocks = 8192;
